@@ -1,0 +1,349 @@
+"""System container, scene compiler and the `solve_system` entry point.
+
+Mirrors src/System.jl: `System(objects)` (:10-21) and
+`solve_system!(system, beam|group; r_max=100)` (:444-468).  The scene is flattened in
+`Leaves` order into the tables of include/bmo.h and handed to the HIP engine through the
+C ABI; the beam trees are rebuilt from the engine's result tables in reference order.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from . import beams as bm
+from . import components as cp
+from . import shapes as sh
+
+# miss-cull inflation of bounding spheres (see DESIGN.md "miss cull")
+_BS_REL, _BS_ABS = 1e-6, 1e-6
+
+
+class System:
+    """src/System.jl:10-21"""
+
+    def __init__(self, objects):
+        self.objects_tree = list(objects) if isinstance(objects, (list, tuple)) else [objects]
+
+    def objects(self):
+        return cp.leaves(self.objects_tree)
+
+
+StaticSystem = System  # src/System.jl:38-45: same tracing semantics
+
+
+class CompiledScene:
+    """Flat tables + the ctypes descriptor that points into them (kept alive together)."""
+
+    def __init__(self, system, lambdas, cull=True, consts=None):
+        objs = system.objects() if isinstance(system, System) else cp.leaves(system)
+        self.leaf_objects = objs
+        self.lambdas = np.array(sorted(set(float(l) for l in lambdas)), dtype=np.float64)
+        self.shape_list = []   # python shape per shape id
+        self._shape_ids = {}
+        shapes, children, tris = [], [], []
+        media, media_ids = [], {}
+
+        def medium_of(fn):
+            key = id(fn)
+            if key not in media_ids:
+                media_ids[key] = len(media)
+                media.append([float(fn(l)) for l in self.lambdas])
+            return media_ids[key]
+
+        def add_shape(s):
+            if id(s) in self._shape_ids:
+                return self._shape_ids[id(s)]
+            rec = abi.Shape()
+            sid = len(shapes)
+            shapes.append(rec)
+            self.shape_list.append(s)
+            self._shape_ids[id(s)] = sid
+            rec.kind = s.kind
+            rec.child_begin = rec.child_count = rec.tri_begin = rec.tri_count = rec.flags = 0
+            rec.pos[:] = list(s.pos)
+            rec.dir[:] = list(np.asarray(s.dir, dtype=np.float64).reshape(9))
+            tdir = s.tdir if hasattr(s, "tdir") else np.asarray(s.dir).T
+            rec.tdir[:] = list(np.asarray(tdir, dtype=np.float64).reshape(9))
+            p = list(s.params()) if hasattr(s, "params") else []
+            rec.p[:] = p + [0.0] * (abi.NPARAM - len(p))
+            if s.kind == sh.K_MESH:
+                t = s.triangles()
+                rec.tri_begin = len(tris)
+                rec.tri_count = len(t)
+                tris.extend(t)
+                v = s.vertices
+                c = (v.min(axis=0) + v.max(axis=0)) / 2
+                r = float(np.sqrt(((v - c) ** 2).sum(axis=1)).max())
+            elif s.kind in (sh.K_UNION, sh.K_MENISCUS):
+                ids = [add_shape(ch) for ch in s.sdfs]
+                rec.child_begin = len(children)
+                rec.child_count = len(ids)
+                children.extend(ids)
+                c, r = s.world_bound()
+            else:
+                c, r = s.world_bound()
+            if cull:
+                rec.bs_center[:] = list(c)
+                rec.bs_radius = r * (1 + _BS_REL) + _BS_ABS
+            else:
+                rec.bs_center[:] = [0.0, 0.0, 0.0]
+                rec.bs_radius = -1.0
+            return sid
+
+        objects = []
+        self.detectors = []
+        for o in objs:
+            rec = abi.Object()
+            rec.kind = o.kind
+            rec.shape[:] = [-1, -1, -1]
+            rec.medium[:] = [-1, -1]
+            rec.detector = -1
+            rec.reflectance = rec.transmittance = rec.cutoff = 0.0
+            parts = o.parts()
+            for k, s in enumerate(parts):
+                rec.shape[k] = add_shape(s)
+            if o.kind == cp.O_REFRACTIVE:
+                rec.medium[0] = medium_of(o.n)
+            elif o.kind == cp.O_DOUBLET:
+                rec.medium[0] = medium_of(o.front.n)
+                rec.medium[1] = medium_of(o.back.n)
+            elif o.kind == cp.O_THIN_BS:
+                rec.reflectance, rec.transmittance = o.reflectance, o.transmittance
+            elif o.kind == cp.O_PLATE_BS:
+                rec.medium[0] = medium_of(o.substrate.n)
+                rec.reflectance, rec.transmittance = o.coating.reflectance, o.coating.transmittance
+            elif o.kind == cp.O_CUBE_BS:
+                rec.medium[0] = medium_of(o.front.n)
+                rec.medium[1] = medium_of(o.back.n)
+                rec.reflectance, rec.transmittance = o.coating.reflectance, o.coating.transmittance
+            elif o.kind in (cp.O_SPOT, cp.O_PSF):
+                rec.detector = len(self.detectors)
+                self.detectors.append(o)
+            elif o.kind == cp.O_POLARIZER:
+                rec.cutoff = o.cutoff
+                j = np.asarray(o.jones, dtype=np.complex128).reshape(9)
+                rec.jones[:] = [x for z in j for x in (z.real, z.imag)]
+            objects.append(rec)
+
+        self.n_objects = len(objects)
+        self._objects = (abi.Object * max(1, len(objects)))(*objects)
+        self._shapes = (abi.Shape * max(1, len(shapes)))(*shapes)
+        self._children = np.array(children if children else [0], dtype=np.int32)
+        self._tris = np.array(tris if tris else [[0.0] * 9], dtype=np.float64).reshape(-1)
+        self._ntab = np.array(media if media else [[1.0] * max(1, len(self.lambdas))], dtype=np.float64).reshape(-1)
+        d = abi.SceneDesc()
+        d.abi_version = abi.ABI_VERSION
+        d.n_objects, d.n_shapes, d.n_children = len(objects), len(shapes), len(children)
+        d.n_tris, d.n_media, d.n_lambda, d.n_detectors = len(tris), len(media), len(self.lambdas), len(self.detectors)
+        d.objects = C.cast(self._objects, C.POINTER(abi.Object))
+        d.shapes = C.cast(self._shapes, C.POINTER(abi.Shape))
+        d.children = self._children.ctypes.data_as(C.POINTER(C.c_int32))
+        d.tris = self._tris.ctypes.data_as(C.POINTER(C.c_double))
+        d.n_table = self._ntab.ctypes.data_as(C.POINTER(C.c_double))
+        d.lambdas = self.lambdas.ctypes.data_as(C.POINTER(C.c_double))
+        k = dict(eps_srf=1e-9, eps_ray=1e-10, eps_ins=1.0, mt_keps=1e-9, mt_leps=1e-9, grad_h=1e-8, march_iters=1000)
+        k.update(consts or {})
+        for name, val in k.items():
+            setattr(d, name, val)
+        self.desc = d
+
+    def shape_id(self, shape):
+        return self._shape_ids[id(shape)]
+
+    def lambda_index(self, lams):
+        lams = np.asarray(lams, dtype=np.float64)
+        idx = np.searchsorted(self.lambdas, lams)
+        if np.any(idx >= len(self.lambdas)) or np.any(self.lambdas[np.minimum(idx, len(self.lambdas) - 1)] != lams):
+            raise KeyError("wavelength not in the compiled lambda table")
+        return idx.astype(np.int32)
+
+
+def make_batch(scene, bundle):
+    """bmo_ray_batch for a RayBundle; returns (batch, keepalive)."""
+    li = scene.lambda_index(bundle.lambdas)
+    planes = np.ascontiguousarray(bundle.planes, dtype=np.float64)
+    b = abi.RayBatch()
+    b.n = bundle.n
+    b.kind = bundle.kind
+    b.n_planes = planes.shape[0]
+    b.planes = planes.ctypes.data_as(C.POINTER(C.c_double))
+    b.lambda_idx = li.ctypes.data_as(C.POINTER(C.c_int32))
+    return b, (planes, li)
+
+
+class Engine:
+    """Thin RAII wrapper over the C ABI for one compiled scene."""
+
+    def __init__(self, scene, device=0):
+        self.lib = abi.load_engine()
+        self.scene = scene
+        self.device = device
+        self.handle = C.c_void_p()
+        abi.check(self.lib, self.lib.bmo_scene_create(C.byref(scene.desc), C.byref(self.handle)), "bmo_scene_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.bmo_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def opts(self, r_max, record_segments=True):
+        o = abi.TraceOpts()
+        o.r_max, o.device, o.record_segments, o.reserved = int(r_max), int(self.device), int(bool(record_segments)), 0
+        return o
+
+    def trace(self, bundle, r_max=100):
+        """bmo_trace: upload + trace + download; returns abi.TraceResult."""
+        batch, keep = make_batch(self.scene, bundle)
+        res = C.c_void_p()
+        o = self.opts(r_max)
+        abi.check(self.lib, self.lib.bmo_trace(self.handle, C.byref(batch), C.byref(o), C.byref(res)), "bmo_trace")
+        try:
+            v = abi.ResultView()
+            abi.check(self.lib, self.lib.bmo_result_view(res, C.byref(v)), "bmo_result_view")
+            out = abi.TraceResult(v)
+            ms, tot, nl = C.c_double(), C.c_double(), C.c_int32()
+            self.lib.bmo_result_timing(res, C.byref(ms), C.byref(tot), C.byref(nl))
+            out.kernel_ms, out.total_ms, out.n_launches = ms.value, tot.value, nl.value
+        finally:
+            self.lib.bmo_result_free(res)
+        return out
+
+    # split form (inputs resident in HBM)
+    def upload(self, bundle):
+        batch, keep = make_batch(self.scene, bundle)
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.bmo_batch_upload(self.handle, C.byref(batch), self.device, C.byref(h)), "bmo_batch_upload")
+        return h
+
+    def free_batch(self, h):
+        self.lib.bmo_batch_free(h)
+
+    def trace_device(self, dev_batch, r_max=100, record_segments=True):
+        res = C.c_void_p()
+        o = self.opts(r_max, record_segments)
+        abi.check(self.lib, self.lib.bmo_trace_device(self.handle, dev_batch, C.byref(o), C.byref(res)), "bmo_trace_device")
+        return res
+
+    def result_timing(self, res):
+        ms, tot, nl = C.c_double(), C.c_double(), C.c_int32()
+        abi.check(self.lib, self.lib.bmo_result_timing(res, C.byref(ms), C.byref(tot), C.byref(nl)), "bmo_result_timing")
+        return ms.value, tot.value, nl.value
+
+    def result_view(self, res):
+        v = abi.ResultView()
+        abi.check(self.lib, self.lib.bmo_result_view(res, C.byref(v)), "bmo_result_view")
+        return abi.TraceResult(v)
+
+    def result_device_hits(self, res, slot):
+        p = C.POINTER(C.c_double)()
+        n = C.c_int64()
+        abi.check(self.lib, self.lib.bmo_result_device_hits(res, slot, C.byref(p), C.byref(n)), "bmo_result_device_hits")
+        return C.cast(p, C.c_void_p).value or 0, n.value
+
+    def free_result(self, res):
+        self.lib.bmo_result_free(res)
+
+
+# ----------------------------------------------------------------------------------------
+def _fill_beams(scene, res, roots):
+    """Rebuild Beam / GaussianBeamlet trees in reference order from a TraceResult."""
+    objs = scene.leaf_objects
+    shapes = scene.shape_list
+    kind = res.beam_kind
+    nodes = [None] * res.n_nodes
+
+    def make_rays(node, base, first):
+        rays = []
+        f, n = int(res.node_first_rec[node]), int(res.node_nseg[node])
+        lam = res.node_aux[node, 3] if kind == bm.BEAM_GAUSSIAN else res.node_aux[node, 0]
+        for r in range(f, f + n):
+            P = res.rec[:, r]
+            if kind == bm.BEAM_POLARIZED:
+                ray = bm.PolarizedRay.__new__(bm.PolarizedRay)
+                ray.E0 = P[11:17:2] + 1j * P[12:17:2]
+            else:
+                ray = bm.Ray.__new__(bm.Ray)
+            ray.pos = P[base:base + 3].copy()
+            ray.dir = P[base + 3:base + 6].copy()
+            ray.n = float(P[base + 6])
+            ray.lam = float(lam)
+            t = float(P[base + 7])
+            if np.isfinite(t):
+                o, s = int(res.rec_obj[r]), int(res.rec_shape[r])
+                ray.intersection = bm.Intersection(t, P[base + 8:base + 11].copy(), objs[o] if o >= 0 else None,
+                                                   shapes[s] if s >= 0 else None)
+            else:
+                ray.intersection = None
+            rays.append(ray)
+        return rays
+
+    for i in range(res.n_nodes):
+        par = int(res.node_parent[i])
+        if par < 0:
+            b = roots[int(res.node_root[i])]
+        elif kind == bm.BEAM_GAUSSIAN:
+            b = bm.GaussianBeamlet(None, None, _parts=(bm.Beam.__new__(bm.Beam), bm.Beam.__new__(bm.Beam), bm.Beam.__new__(bm.Beam),
+                                                       0.0, 0.0, 0j))
+            for sub in (b.chief, b.waist, b.divergence):
+                sub.parent, sub.children, sub.status = None, [], 0
+        else:
+            b = bm.Beam.__new__(bm.Beam)
+            b.parent, b.children, b.status = None, [], 0
+        nodes[i] = b
+        b.status = int(res.node_status[i])
+        b.children = []
+        if kind == bm.BEAM_GAUSSIAN:
+            b.chief.rays = make_rays(i, 0, True)
+            b.waist.rays = make_rays(i, 11, False)
+            b.divergence.rays = make_rays(i, 22, False)
+            b.w0 = float(res.node_aux[i, 0])
+            b.E0 = complex(res.node_aux[i, 1], res.node_aux[i, 2])
+            b.lam = float(res.node_aux[i, 3])
+        else:
+            b.rays = make_rays(i, 0, True)
+        if par >= 0:
+            p = nodes[par]
+            b.parent = p
+            p.children.append(b)
+            if kind == bm.BEAM_GAUSSIAN:
+                b.chief.parent = p.chief  # parent! Gaussian.jl:113-117
+    return nodes
+
+
+def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=None):
+    """solve_system!(system, beam | beam group; r_max=100) — src/System.jl:444-468.
+
+    Fresh (unsolved) beams only: the retrace pass of the reference is a no-op for them
+    (System.jl:197-206).  Mutates the beam objects (rays, intersections, children) and
+    appends detector data, exactly like the reference.  Returns the raw TraceResult.
+    """
+    if isinstance(beams, bm.BeamGroup):
+        roots = beams.beams
+    elif isinstance(beams, (list, tuple)):
+        roots = list(beams)
+    else:
+        roots = [beams]
+    bundle = bm.RayBundle.from_beams(roots)
+    scene = CompiledScene(system, bundle.lambdas)
+    if _trace_fn is None:
+        eng = Engine(scene, device)
+        try:
+            res = eng.trace(bundle, r_max)
+        finally:
+            eng.close()
+    else:
+        res = _trace_fn(scene, bundle, r_max)
+    _fill_beams(scene, res, roots)
+    for slot, det in enumerate(scene.detectors):
+        hits = res.detector_hits(slot)
+        if det.kind == cp.O_SPOT:
+            det.data = np.concatenate([det.data, hits[:, 0:2]], axis=0)
+        else:
+            det.data = np.concatenate([det.data, hits], axis=0)
+    return res

@@ -1,0 +1,264 @@
+/*
+ * bmo.h — C ABI of the MI355X-native trace engine for BeamletOptics.jl's hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the
+ * entry points below replace, for a whole batch of beams at once,
+ *
+ *   solve_system!(system, bg::AbstractBeamGroup; r_max, retrace)   src/System.jl:463-468
+ *   solve_system!(system, beam::AbstractBeam;   r_max, retrace)    src/System.jl:444-461
+ *     -> trace_system!(system, beam::Beam)                          src/System.jl:130-154
+ *     -> trace_system!(system, gauss::GaussianBeamlet)              src/System.jl:274-318
+ *     -> tracing_step! / trace_one / trace_all                      src/System.jl:57-110
+ *     -> intersect3d(object|shape, ray)                             src/AbstractTypes/AbstractRay.jl:118-155,
+ *                                                                   src/Mesh.jl:244-267, src/SDFs/AbstractSDF.jl:166-181
+ *     -> interact3d(system, object, beam, ray)                      src/OpticalComponents/ (all files)
+ *
+ * Everything is plain C: pointers + sizes, FP64, SI metres.  No exceptions cross
+ * the boundary: functions return 0 on success or a negative bmo_status code and
+ * bmo_last_error() gives the thread-local message.  Data-dependent faults that
+ * are exceptions in the reference (non-unit vectors OpticUtils.jl:33-35, ...)
+ * are reported per beam node in node_status so the wrapper can re-raise them.
+ *
+ * The library is libbmo_hip.so (HIP, gfx950).  There is no CPU fallback inside
+ * it: every trace call needs a GPU and fails with BMO_ERR_NO_DEVICE otherwise.
+ * The independent CPU restatement of the reference algorithm lives in oracle/
+ * (test infrastructure) and exports bmo_cpu_trace() with the same descriptor.
+ */
+#ifndef BMO_H
+#define BMO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMO_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status */
+enum bmo_status {
+    BMO_OK = 0,
+    BMO_ERR_INVALID = -1,     /* bad descriptor / argument                     */
+    BMO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure           */
+    BMO_ERR_OOM = -3,         /* device or host allocation failed              */
+    BMO_ERR_UNSUPPORTED = -4, /* shape/object/beam kind not built yet          */
+    BMO_ERR_INTERNAL = -5
+};
+
+/* per-node status bits (node_status) */
+enum bmo_node_status {
+    BMO_NODE_MISS = 1,        /* last segment found no intersection (System.jl:142-144)   */
+    BMO_NODE_STOPPED = 2,     /* interact3d returned nothing (System.jl:147-149)          */
+    BMO_NODE_RMAX = 4,        /* length(rays) reached r_max (System.jl:133)               */
+    BMO_NODE_SPLIT = 8,       /* children!(beam,[t,r]) was called (ThinBeamsplitter.jl:108-115) */
+    BMO_NODE_DETECTED = 16,   /* a detector recorded this beam                            */
+    BMO_NODE_ERR_UNIT = 32,   /* refraction3d unit-length ArgumentError (OpticUtils.jl:33-35) */
+    BMO_NODE_GAUSS_DIVERGED = 64, /* chief/waist/div did not hit same shape (System.jl:298-304) */
+    BMO_NODE_BLOCKED = 128    /* PolarizationFilter blocked ray (PolarizationFilter.jl:42) */
+};
+
+/* ------------------------------------------------------------------ shapes */
+enum bmo_shape_kind {
+    BMO_SHAPE_MESH = 0,        /* src/Mesh.jl:33-39;  tri_begin/tri_count, world-space vertices   */
+    BMO_SHAPE_SPHERE = 1,      /* SphericalLensSDF.jl:72-89   p = {radius}                         */
+    BMO_SHAPE_PLANO = 2,       /* SphericalLensSDF.jl:41-65   p = {thickness, diameter}            */
+    BMO_SHAPE_CONVEX = 3,      /* SphericalLensSDF.jl:186-232 p = {radius, diameter, sag, height}  */
+    BMO_SHAPE_CONCAVE = 4,     /* SphericalLensSDF.jl:131-170 p = {radius, diameter, sag}          */
+    BMO_SHAPE_UNION = 5,       /* UnionSDF.jl:22-91           children                             */
+    BMO_SHAPE_BOX = 6,         /* PrimitiveSDF.jl:13-46       p = {hx, hy, hz} half edge lengths   */
+    BMO_SHAPE_CYLINDER = 7,    /* PrimitiveSDF.jl:53-76       p = {radius, height}                 */
+    BMO_SHAPE_CUTSPHERE = 8,   /* PrimitiveSDF.jl:83-124      p = {radius, height, w}              */
+    BMO_SHAPE_RING = 9,        /* PrimitiveSDF.jl:132-166     p = {inner_radius, hwidth, hthickness} */
+    BMO_SHAPE_PRISM = 10,      /* PrimitiveSDF.jl:183-210     p = {hx, hy, hz}                     */
+    BMO_SHAPE_MENISCUS = 11,   /* MeniscusLensSDF.jl:19-46    children = {convex, cylinder, concave} in the meniscus frame */
+    BMO_SHAPE_POINT = 12,      /* test/runtests.jl:926-947 TestPointSDF: sdf = norm(p)             */
+    BMO_SHAPE_KIND_COUNT
+};
+
+#define BMO_SHAPE_NPARAM 8
+
+typedef struct bmo_shape {
+    int32_t kind;
+    int32_t child_begin;   /* index into bmo_scene_desc.children (UNION, MENISCUS) */
+    int32_t child_count;
+    int32_t tri_begin;     /* MESH: first triangle                                   */
+    int32_t tri_count;
+    int32_t flags;         /* reserved, 0                                            */
+    double pos[3];         /* position(shape)                                        */
+    double dir[9];         /* orientation(shape), row-major 3x3                      */
+    double tdir[9];        /* transposed_orientation(shape) (AbstractSDF.jl:20-27), row-major;
+                              identity for SPHERE (SphericalLensSDF.jl:82-84)        */
+    double p[BMO_SHAPE_NPARAM];
+    /* Conservative world-space bounding sphere, used ONLY for the provably
+       equivalent miss shortcut (DESIGN.md "miss cull"); radius < 0 disables it. */
+    double bs_center[3];
+    double bs_radius;
+} bmo_shape;
+
+/* ----------------------------------------------------------------- objects */
+enum bmo_object_kind {
+    BMO_OBJ_MIRROR = 0,          /* AbstractReflectiveOptic   Mirrors.jl:39-69                    */
+    BMO_OBJ_REFRACTIVE = 1,      /* Lens / Prism              Lenses.jl:46-126                    */
+    BMO_OBJ_DOUBLET = 2,         /* DoubletLens               DoubletLenses.jl:26-76  shape={front,back} medium={n1,n2} */
+    BMO_OBJ_THIN_BS = 3,         /* ThinBeamsplitter          ThinBeamsplitter.jl:16-168          */
+    BMO_OBJ_PLATE_BS = 4,        /* plate splitter            PlateBeamsplitter.jl:160-275 shape={substrate,coating}    */
+    BMO_OBJ_CUBE_BS = 5,         /* cube splitter             CubeBeamsplitter.jl:63-121   shape={front,back,coating}   */
+    BMO_OBJ_SPOTDETECTOR = 6,    /* Spotdetector.jl:50-61                                         */
+    BMO_OBJ_PSFDETECTOR = 7,     /* PSFDetector.jl:77-89                                          */
+    BMO_OBJ_INTERSECTABLE = 8,   /* Intersectable.jl:15                                           */
+    BMO_OBJ_NONINTERACTABLE = 9, /* NonInteractable.jl:19-20                                      */
+    BMO_OBJ_POLARIZER = 10,      /* PolarizationFilter.jl:31-48                                   */
+    BMO_OBJ_KIND_COUNT
+};
+
+typedef struct bmo_object {
+    int32_t kind;
+    int32_t shape[3];      /* part shapes, -1 when unused (see kind)                 */
+    int32_t medium[2];     /* rows of n_table for refractive parts, -1 when unused   */
+    int32_t detector;      /* detector slot (0..n_detectors-1) or -1                 */
+    int32_t reserved;
+    double reflectance;    /* amplitude R (ThinBeamsplitter.jl:47-50)                */
+    double transmittance;  /* amplitude T                                            */
+    double cutoff;         /* PolarizationFilter cutoff                              */
+    double jones[18];      /* GlobalJonesBasis 3x3 complex, row-major (re,im) pairs  */
+} bmo_object;
+
+/* ------------------------------------------------------------------- scene */
+typedef struct bmo_scene_desc {
+    int32_t abi_version;   /* BMO_ABI_VERSION */
+    int32_t n_objects;     /* leaf objects in Leaves() order (System.jl:21)          */
+    int32_t n_shapes;
+    int32_t n_children;
+    int32_t n_tris;
+    int32_t n_media;
+    int32_t n_lambda;
+    int32_t n_detectors;
+    const bmo_object* objects;
+    const bmo_shape* shapes;
+    const int32_t* children;  /* shape ids                                           */
+    const double* tris;       /* 9 doubles per triangle: V1 V2 V3 (world space)      */
+    const double* n_table;    /* [n_media][n_lambda]: n_obj(lambda) evaluated by the host
+                                 (RefractiveIndexUtils.jl functors cannot cross a C ABI) */
+    const double* lambdas;    /* [n_lambda] distinct wavelengths of the batch        */
+    /* tracing constants; the reference's compile-time values are the defaults */
+    double eps_srf;        /* 1e-9  AbstractSDF.jl:1  */
+    double eps_ray;        /* 1e-10 AbstractSDF.jl:2  */
+    double eps_ins;        /* 1.0   AbstractSDF.jl:3  */
+    double mt_keps;        /* 1e-9  Mesh.jl:203       */
+    double mt_leps;        /* 1e-9  Mesh.jl:203       */
+    double grad_h;         /* 1e-8  AbstractSDF.jl:83 */
+    int32_t march_iters;   /* 1000  AbstractSDF.jl:105,135 */
+    int32_t reserved;
+} bmo_scene_desc;
+
+typedef struct bmo_scene bmo_scene; /* opaque, immutable after create, shareable */
+
+/* ------------------------------------------------------------------- beams */
+enum bmo_beam_kind {
+    BMO_BEAM_RAY = 0,        /* Beam{T,Ray{T}}           Rays.jl:14-20        */
+    BMO_BEAM_POLARIZED = 1,  /* Beam{T,PolarizedRay{T}}  PolarizedRays.jl:37-66 */
+    BMO_BEAM_GAUSSIAN = 2    /* GaussianBeamlet          Gaussian.jl:33-42    */
+};
+
+/* Planar (structure-of-arrays) input: plane i occupies planes[i*n .. (i+1)*n).
+ *   RAY        (8 planes):  px py pz dx dy dz lambda n
+ *   POLARIZED  (14 planes): the 8 above, then Re(E0x) Im(E0x) Re(E0y) Im(E0y) Re(E0z) Im(E0z)
+ *   GAUSSIAN   (25 planes): chief px..dz (6), waist px..dz (6), divergence px..dz (6),
+ *                           lambda, n, w0, Re(E0), Im(E0), then 2 reserved (0)
+ * dir must already be normalised by the caller exactly as the Ray constructor does
+ * (Rays.jl:32-42); the engine does not renormalise first segments.               */
+#define BMO_PLANES_RAY 8
+#define BMO_PLANES_POLARIZED 14
+#define BMO_PLANES_GAUSSIAN 25
+
+typedef struct bmo_ray_batch {
+    int64_t n;                  /* number of root beams                              */
+    int32_t kind;               /* bmo_beam_kind                                     */
+    int32_t n_planes;
+    const double* planes;       /* host pointer, n_planes * n doubles                */
+    const int32_t* lambda_idx;  /* [n] index of each beam's wavelength in lambdas    */
+} bmo_ray_batch;
+
+typedef struct bmo_trace_opts {
+    int32_t r_max;              /* solve_system! default 100 (System.jl:444)         */
+    int32_t device;             /* HIP device ordinal                                */
+    int32_t record_segments;    /* 1: keep the full segment log (reference behaviour) */
+    int32_t reserved;
+} bmo_trace_opts;
+
+/* ------------------------------------------------------------------ result
+ * All arrays are owned by the result handle until bmo_result_free.  Nodes are
+ * beam-tree nodes (one Beam / GaussianBeamlet each) in REFERENCE order: bundle
+ * order, and inside one root's tree the BFS order of solve_system! (System.jl:446-458,
+ * transmitted child before reflected child, Beamsplitters.jl:16-19).  Records are
+ * ray segments grouped by node in that order, k = 0..nseg-1 inside a node.
+ * Planes per record:
+ *   RAY:       px py pz dx dy dz n | t nx ny nz                       (11)
+ *   POLARIZED: the 11 above, then Re/Im E0x E0y E0z                   (17)
+ *   GAUSSIAN:  chief(11) waist(11) divergence(11)                     (33)
+ * A record whose ray has no intersection has obj = shape = -1, t = +Inf.          */
+typedef struct bmo_trace_result_view {
+    int64_t n_roots;
+    int64_t n_nodes;
+    int64_t n_records;
+    int64_t n_intersect_calls;  /* intersect3d(object|hint shape, ray) calls the reference
+                                   algorithm performs for this trace (BASELINE metric) */
+    int32_t n_steps;            /* bounce-synchronous kernel launches                */
+    int32_t beam_kind;
+    int32_t rec_planes;         /* planes per record                                 */
+    int32_t n_detectors;
+    const int32_t* node_root;
+    const int32_t* node_parent;       /* node index or -1                            */
+    const int32_t* node_first_child;  /* node index of transmitted child (+1 = reflected) or -1 */
+    const int32_t* node_first_rec;    /* first record of the node                    */
+    const int32_t* node_nseg;         /* length(rays(beam))                          */
+    const int32_t* node_status;       /* bmo_node_status bits                        */
+    const double* node_aux;           /* [n_nodes*4]: GAUSSIAN w0, Re(E0), Im(E0), lambda; else lambda,0,0,0 */
+    const int32_t* rec_obj;           /* Intersection.object as leaf index           */
+    const int32_t* rec_shape;         /* Intersection.shape as shape id              */
+    const double* rec;                /* planar [rec_planes][n_records]              */
+    /* detector hit lists in reference push! order */
+    const int64_t* det_count;         /* [n_detectors]                               */
+    const int64_t* det_offset;        /* [n_detectors] offset into det_data (in hits) */
+    const int32_t* det_node;          /* [total hits] node that produced the hit     */
+    const double* det_data;           /* [total hits][9]: Spot: x z 0..; PSF: hit(3) dir(3) opl proj k */
+} bmo_trace_result_view;
+
+typedef struct bmo_trace_result bmo_trace_result; /* opaque */
+
+/* ---------------------------------------------------------------- functions */
+int bmo_version(void);
+const char* bmo_last_error(void);
+
+/* Number of usable HIP devices (0 = none). */
+int bmo_device_count(void);
+
+int bmo_scene_create(const bmo_scene_desc* desc, bmo_scene** out);
+int bmo_scene_destroy(bmo_scene* scene);
+
+/* One call = solve_system!(system, group; r_max) for a fresh (un-solved) batch:
+ * upload, trace on the device, canonicalise, download.                            */
+int bmo_trace(bmo_scene* scene, const bmo_ray_batch* in, const bmo_trace_opts* opts,
+              bmo_trace_result** out);
+
+/* Split form used by benchmarks and multi-GPU drivers: inputs stay resident in HBM. */
+typedef struct bmo_device_batch bmo_device_batch; /* opaque */
+int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, bmo_device_batch** out);
+int bmo_batch_free(bmo_device_batch* batch);
+/* Runs the whole trace on the device (all bounce steps, child spawning, detector
+ * hit compaction + ordering).  Results stay on the device inside *out; blocks until done. */
+int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts,
+                     bmo_trace_result** out);
+/* Device pointers of the ordered detector hit buffers (for RCCL all-gather):
+ * data = [count][9] doubles on the device the trace ran on.                        */
+int bmo_result_device_hits(bmo_trace_result* res, int32_t detector, const double** data, int64_t* count);
+/* Kernel timing of the last trace: sum over step-kernel launches, HIP events on the trace stream. */
+int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* total_ms, int32_t* n_launches);
+/* Materialise host views (downloads + canonical ordering of the segment log). */
+int bmo_result_view(bmo_trace_result* res, bmo_trace_result_view* view);
+int bmo_result_free(bmo_trace_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMO_H */

@@ -1,0 +1,175 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// jl_math.hpp — scalar / vector / dual-number arithmetic restated from the Julia
+// packages the reference computes with.  Every function states which Julia rule it
+// follows.  The reference itself cannot run here (no julia binary) and
+// the third-party packages are not vendored under /root/reference, so these rules are
+// restated from the packages' published semantics:
+//   * ForwardDiff.jl  (Project.toml compat "0.10, 1.0.1"; call site src/SDFs/AbstractSDF.jl:91)
+//   * DiffRules.jl    (max/min/abs/sqrt derivative rules used by ForwardDiff's Dual)
+//   * GeometryBasics.jl 0.5 (Point2/Point3: norm = sqrt(dot(a,a)), normalize = a ./ norm(a))
+//   * StaticArrays.jl 1  (SMatrix * vector: row-wise left-fold of products; cross; dot)
+//   * LinearAlgebra   (normalize(::Vector) = rmul!(a, inv(norm(a))))
+// Bit-level parity with Julia for these rules is UNPINNED (no reference test pins them
+// bit-exactly); parity at the reference's own tolerances is pinned by the
+// known-answer tests in tests/test_oracle_kat.py.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <limits>
+
+namespace jl {
+
+// ---------------------------------------------------------------------------
+// Julia Base.max / Base.min for Float64 (base/math.jl): NaN-propagating, -0.0 < +0.0.
+inline double jmax(double x, double y) {
+    if (std::isnan(x) || std::isnan(y)) return std::numeric_limits<double>::quiet_NaN();
+    return ((y > x) || (std::signbit(y) < std::signbit(x))) ? y : x;
+}
+inline double jmin(double x, double y) {
+    if (std::isnan(x) || std::isnan(y)) return std::numeric_limits<double>::quiet_NaN();
+    return ((y < x) || (std::signbit(y) > std::signbit(x))) ? y : x;
+}
+inline double jabs(double x) { return std::fabs(x); }
+inline double jsqrt(double x) { return std::sqrt(x); }
+inline double value(double x) { return x; }
+
+// ---------------------------------------------------------------------------
+// ForwardDiff.Dual{T,Float64,3}: value + 3 partials (gradient w.r.t. world x,y,z).
+struct Dual {
+    double v;
+    double p[3];
+};
+inline double value(const Dual& a) { return a.v; }
+inline Dual mkdual(double v, double p0, double p1, double p2) { return Dual{v, {p0, p1, p2}}; }
+
+// +, - : componentwise (ForwardDiff dual.jl @define_binary_dual_op +/-)
+inline Dual operator+(const Dual& a, const Dual& b) { return Dual{a.v + b.v, {a.p[0] + b.p[0], a.p[1] + b.p[1], a.p[2] + b.p[2]}}; }
+inline Dual operator-(const Dual& a, const Dual& b) { return Dual{a.v - b.v, {a.p[0] - b.p[0], a.p[1] - b.p[1], a.p[2] - b.p[2]}}; }
+inline Dual operator+(const Dual& a, double r) { return Dual{a.v + r, {a.p[0], a.p[1], a.p[2]}}; }
+inline Dual operator+(double r, const Dual& a) { return Dual{r + a.v, {a.p[0], a.p[1], a.p[2]}}; }
+inline Dual operator-(const Dual& a, double r) { return Dual{a.v - r, {a.p[0], a.p[1], a.p[2]}}; }
+inline Dual operator-(double r, const Dual& a) { return Dual{r - a.v, {-a.p[0], -a.p[1], -a.p[2]}}; }
+inline Dual operator-(const Dual& a) { return Dual{-a.v, {-a.p[0], -a.p[1], -a.p[2]}}; }
+// * : Dual*Dual = Dual(vx*vy, _mul_partials(px, py, vy, vx)) with
+//     _mul_partials(a, b, x_a, x_b) = a*x_a + b*x_b  (ForwardDiff partials.jl mul_tuples)
+inline Dual operator*(const Dual& a, const Dual& b) {
+    return Dual{a.v * b.v, {(a.p[0] * b.v) + (b.p[0] * a.v), (a.p[1] * b.v) + (b.p[1] * a.v), (a.p[2] * b.v) + (b.p[2] * a.v)}};
+}
+inline Dual operator*(const Dual& a, double r) { return Dual{a.v * r, {a.p[0] * r, a.p[1] * r, a.p[2] * r}}; }
+inline Dual operator*(double r, const Dual& a) { return Dual{r * a.v, {a.p[0] * r, a.p[1] * r, a.p[2] * r}}; }
+// / : Dual/Real = Dual(v/r, partials/r)
+inline Dual operator/(const Dual& a, double r) { return Dual{a.v / r, {a.p[0] / r, a.p[1] / r, a.p[2] / r}}; }
+// comparisons act on values
+inline bool operator<(const Dual& a, const Dual& b) { return a.v < b.v; }
+inline bool operator<(const Dual& a, double b) { return a.v < b; }
+inline bool operator>(const Dual& a, double b) { return a.v > b; }
+
+// sqrt: DiffRules  d/dx sqrt(x) = inv(2*sqrt(x));  Dual(val, deriv * partials)
+inline Dual jsqrt(const Dual& a) {
+    double s = std::sqrt(a.v);
+    double d = 1.0 / (2.0 * s);
+    return Dual{s, {a.p[0] * d, a.p[1] * d, a.p[2] * d}};
+}
+// abs: ForwardDiff dual.jl  Base.abs(d::Dual) = signbit(value(d)) ? -d : d
+inline Dual jabs(const Dual& a) { return std::signbit(a.v) ? -a : a; }
+
+// max/min: ForwardDiff builds them from DiffRules' binary rules:
+//   Dual(max(vx,vy), _mul_partials(px, py, dvx, dvy)),  (dvx,dvy) in {(1,0),(0,1)}
+//   DiffRules:  max: y wins iff (y > x) | (signbit(y) < signbit(x));  min: (y < x) | (signbit(y) > signbit(x))
+// NOTE the multiplication by 0/1: a NaN/Inf partial of the LOSING operand contaminates the result
+// (0*NaN = NaN).  That is what triggers the numeric-gradient fallback of AbstractSDF.jl:92-94.
+inline Dual jmax(const Dual& x, const Dual& y) {
+    bool ywins = (y.v > x.v) || (std::signbit(y.v) < std::signbit(x.v));
+    double dx = ywins ? 0.0 : 1.0, dy = ywins ? 1.0 : 0.0;
+    return Dual{jmax(x.v, y.v), {(x.p[0] * dx) + (y.p[0] * dy), (x.p[1] * dx) + (y.p[1] * dy), (x.p[2] * dx) + (y.p[2] * dy)}};
+}
+inline Dual jmin(const Dual& x, const Dual& y) {
+    bool ywins = (y.v < x.v) || (std::signbit(y.v) > std::signbit(x.v));
+    double dx = ywins ? 0.0 : 1.0, dy = ywins ? 1.0 : 0.0;
+    return Dual{jmin(x.v, y.v), {(x.p[0] * dx) + (y.p[0] * dy), (x.p[1] * dx) + (y.p[1] * dy), (x.p[2] * dx) + (y.p[2] * dy)}};
+}
+// Dual vs Real: Dual(val, dvx * partials(x))
+inline Dual jmax(const Dual& x, double y) {
+    bool ywins = (y > x.v) || (std::signbit(y) < std::signbit(x.v));
+    double dx = ywins ? 0.0 : 1.0;
+    return Dual{jmax(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
+}
+inline Dual jmin(const Dual& x, double y) {
+    bool ywins = (y < x.v) || (std::signbit(y) > std::signbit(x.v));
+    double dx = ywins ? 0.0 : 1.0;
+    return Dual{jmin(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
+}
+
+// ---------------------------------------------------------------------------
+template <class T>
+struct V3 {
+    T x, y, z;
+};
+template <class T>
+struct V2 {
+    T x, y;
+};
+using D3 = V3<double>;
+
+// elementwise ops (GeometryBasics Point broadcasting)
+template <class T> inline V3<T> operator+(const V3<T>& a, const V3<T>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> inline V3<T> operator-(const V3<T>& a, const V3<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> inline V3<T> operator-(const V3<T>& a) { return {-a.x, -a.y, -a.z}; }
+template <class T> inline V3<T> operator*(double s, const V3<T>& a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> inline V2<T> operator-(const V2<T>& a, const V2<T>& b) { return {a.x - b.x, a.y - b.y}; }
+
+// dot: left fold a1*b1 + a2*b2 + a3*b3
+template <class T> inline T dot(const V3<T>& a, const V3<T>& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <class T> inline T dot(const V2<T>& a, const V2<T>& b) { return a.x * b.x + a.y * b.y; }
+// norm = sqrt(dot(a,a))
+template <class T> inline T norm(const V3<T>& a) { return jsqrt(dot(a, a)); }
+template <class T> inline T norm(const V2<T>& a) { return jsqrt(dot(a, a)); }
+// cross (StaticArrays / GeometryBasics): (a2*b3-a3*b2, a3*b1-a1*b3, a1*b2-a2*b1)
+inline D3 cross(const D3& a, const D3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// normalize(::Point3) = a ./ norm(a)  (GeometryBasics 0.5)
+inline D3 normalize_pt(const D3& a) {
+    double n = norm(a);
+    return {a.x / n, a.y / n, a.z / n};
+}
+// normalize(::Vector) = a * inv(norm(a))  (LinearAlgebra.__normalize!, used on ForwardDiff.gradient's Vector result)
+inline D3 normalize_vec(const D3& a) {
+    double n = norm(a);
+    double inv = 1.0 / n;
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+// 3x3 row-major matrix times vector: each row left-folded (StaticArrays _mul)
+template <class T>
+inline V3<T> matvec(const double* m, const V3<T>& v) {
+    return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z, (m[6] * v.x + m[7] * v.y) + m[8] * v.z};
+}
+
+// isapprox(x, y; atol, rtol) for reals: |x-y| <= max(atol, rtol*max(|x|,|y|));
+// default rtol = sqrt(eps) only when atol == 0 (Base floatfuncs.jl)
+inline bool isapprox(double x, double y, double atol = 0.0) {
+    double rtol = atol > 0.0 ? 0.0 : 1.4901161193847656e-08;
+    if (x == y) return true;
+    if (!std::isfinite(x) || !std::isfinite(y)) return false;
+    return std::fabs(x - y) <= std::fmax(atol, rtol * std::fmax(std::fabs(x), std::fabs(y)));
+}
+
+// simple complex with textbook formulas (shared convention with the device code; Julia's
+// Complex division/sqrt use scaled algorithms that differ in the last ulp — unpinned)
+struct Cx {
+    double re, im;
+};
+inline Cx operator+(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
+inline Cx operator-(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
+inline Cx operator-(Cx a) { return {-a.re, -a.im}; }
+inline Cx operator*(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline Cx operator*(double s, Cx a) { return {s * a.re, s * a.im}; }
+inline Cx operator*(Cx a, double s) { return {a.re * s, a.im * s}; }
+inline Cx operator/(Cx a, Cx b) {
+    double den = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+}
+inline double abs2(Cx a) { return a.re * a.re + a.im * a.im; }
+inline Cx csqrt_real(double x) { return x >= 0.0 ? Cx{std::sqrt(x), 0.0} : Cx{0.0, std::sqrt(-x)}; }
+
+}  // namespace jl

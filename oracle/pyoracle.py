@@ -1,0 +1,135 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes wrapper over oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import bmo_amd as bmo
+from bmo_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        dp = C.POINTER(C.c_double)
+        L.bmo_cpu_trace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.c_int,
+                                    C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
+        L.bmo_cpu_result_free.argtypes = [C.c_void_p]
+        L.bmo_cpu_last_error.restype = C.c_char_p
+        L.bmo_cpu_sdf.restype = C.c_double
+        L.bmo_cpu_sdf.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, dp]
+        L.bmo_cpu_normal3d.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, dp, dp]
+        L.bmo_cpu_intersect_shape.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, dp, dp, dp, dp]
+        L.bmo_cpu_intersect_object.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int)]
+        L.bmo_cpu_moeller_trumbore.restype = C.c_double
+        L.bmo_cpu_moeller_trumbore.argtypes = [dp, dp, dp]
+        L.bmo_cpu_reflection3d.argtypes = [dp, dp, dp]
+        L.bmo_cpu_refraction3d.argtypes = [dp, dp, C.c_double, C.c_double, dp]
+        L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
+        L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def trace(scene, bundle, r_max=100, threads=1):
+    """Reference-algorithm CPU trace -> abi.TraceResult (same layout as the engine's)."""
+    L = lib()
+    batch, keep = bmo.make_batch(scene, bundle)
+    o = abi.TraceOpts()
+    o.r_max, o.device, o.record_segments, o.reserved = int(r_max), 0, 1, 0
+    h = C.c_void_p()
+    v = abi.ResultView()
+    rc = L.bmo_cpu_trace(C.byref(scene.desc), C.byref(batch), C.byref(o), int(threads), C.byref(h), C.byref(v))
+    if rc != 0:
+        raise RuntimeError(f"bmo_cpu_trace failed: {L.bmo_cpu_last_error().decode()}")
+    try:
+        return abi.TraceResult(v)
+    finally:
+        L.bmo_cpu_result_free(h)
+
+
+def solve_system(system, beams, r_max=100, threads=1):
+    """solve_system! computed by the oracle (fills the same Python beam objects)."""
+    return bmo.solve_system(system, beams, r_max=r_max, _trace_fn=lambda sc, b, rm: trace(sc, b, rm, threads))
+
+
+def sdf(scene, shape, p):
+    a, pa = _d(p)
+    return lib().bmo_cpu_sdf(C.byref(scene.desc), scene.shape_id(shape), pa)
+
+
+def normal3d(scene, shape, p):
+    a, pa = _d(p)
+    out, po = _d(np.zeros(3))
+    lib().bmo_cpu_normal3d(C.byref(scene.desc), scene.shape_id(shape), pa, po)
+    return out
+
+
+def intersect_shape(scene, shape, pos, dir):
+    a, pa = _d(pos)
+    b, pb = _d(dir)
+    n, pn = _d(np.zeros(3))
+    t = C.c_double()
+    hit = lib().bmo_cpu_intersect_shape(C.byref(scene.desc), scene.shape_id(shape), pa, pb, C.byref(t), pn)
+    return (t.value, n) if hit == 1 else None
+
+
+def intersect_object(scene, obj_index, pos, dir):
+    a, pa = _d(pos)
+    b, pb = _d(dir)
+    n, pn = _d(np.zeros(3))
+    t = C.c_double()
+    s = C.c_int()
+    hit = lib().bmo_cpu_intersect_object(C.byref(scene.desc), obj_index, pa, pb, C.byref(t), pn, C.byref(s))
+    return (t.value, n, s.value) if hit == 1 else None
+
+
+def moeller_trumbore(face, pos, dir):
+    f, pf = _d(np.asarray(face, dtype=np.float64).reshape(9))
+    a, pa = _d(pos)
+    b, pb = _d(dir)
+    return lib().bmo_cpu_moeller_trumbore(pf, pa, pb)
+
+
+def reflection3d(dir, normal):
+    a, pa = _d(dir)
+    b, pb = _d(normal)
+    o, po = _d(np.zeros(3))
+    lib().bmo_cpu_reflection3d(pa, pb, po)
+    return o
+
+
+def refraction3d(dir, normal, n1, n2):
+    a, pa = _d(dir)
+    b, pb = _d(normal)
+    o, po = _d(np.zeros(3))
+    rc = lib().bmo_cpu_refraction3d(pa, pb, n1, n2, po)
+    if rc < 0:
+        raise ValueError("dir/normal must have unit length")
+    return o, bool(rc)
+
+
+def fresnel_coefficients(theta, n):
+    o, po = _d(np.zeros(8))
+    lib().bmo_cpu_fresnel(theta, n, po)
+    return complex(o[0], o[1]), complex(o[2], o[3]), complex(o[4], o[5]), complex(o[6], o[7])

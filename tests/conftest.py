@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+if ORACLE_DIR not in sys.path:
+    sys.path.insert(0, ORACLE_DIR)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle
+
+    pyoracle.lib()
+    return pyoracle

@@ -1,0 +1,328 @@
+"""Known-answer tests of the reference (test/runtests.jl) transcribed against the CPU oracle.
+
+These pin the oracle: every test cites the runtests.jl lines it restates and uses
+the reference's own tolerance.  `approx(a, b)` is Julia's isapprox (rtol = sqrt(eps) unless atol).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bmo_amd as bmo
+
+RTOL = math.sqrt(np.finfo(float).eps)
+
+
+def approx(a, b, atol=0.0):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    rtol = 0.0 if atol > 0 else RTOL
+    return np.linalg.norm(a - b) <= max(atol, rtol * max(np.linalg.norm(a), np.linalg.norm(b)))
+
+
+def angle3d(a, b):
+    return math.acos(max(-1.0, min(1.0, np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))))
+
+
+def scene_of(objs, lambdas=(1e-6,), **kw):
+    return bmo.CompiledScene(bmo.System(objs), lambdas, **kw)
+
+
+# ------------------------------------------------------------------ utils (runtests.jl:83-195)
+def test_reflection3d(oracle):  # :83-88
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            assert approx(oracle.reflection3d([dx, dy, 1], [0, 0, -1]), [dx, dy, -1])
+
+
+def _thetas():
+    small = np.arange(0, 5e-5 + 1e-12, 1e-7)
+    large = np.arange(small[-1], math.pi / 2, math.pi / 1000)
+    return np.concatenate([small, large])
+
+
+def test_refraction3d_vacuum_to_medium(oracle):  # :96-111
+    normal = np.array([0.0, 0, 1])
+    n1, n2 = 1.0, 1.62286
+    num, ana = [], []
+    for th in _thetas():
+        out, tir = oracle.refraction3d([math.sin(th), 0, -math.cos(th)], normal, n1, n2)
+        assert not tir
+        num.append(angle3d(-normal, out))
+        ana.append(math.asin(n1 / n2 * math.sin(th)))
+    assert approx(num, ana)
+
+
+def test_refraction3d_medium_to_vacuum(oracle):  # :112-138
+    normal = np.array([0.0, 0, 1])
+    n1, n2 = 1.62286, 1.0
+    a2, a3 = [], []
+    for th in _thetas():
+        out, tir = oracle.refraction3d([math.sin(th), 0, -math.cos(th)], normal, n1, n2)
+        if th > math.asin(n2 / n1):
+            a2.append(angle3d(out, normal))
+            a3.append(th)
+            assert tir
+        else:
+            a2.append(angle3d(-normal, out))
+            a3.append(math.asin(n1 / n2 * math.sin(th)))
+            assert not tir
+    assert approx(a2, a3)
+
+
+def test_refraction3d_unit_length_error(oracle):  # OpticUtils.jl:33-35
+    with pytest.raises(ValueError):
+        oracle.refraction3d([0, 0, -2.0], [0, 0, 1.0], 1.0, 1.5)
+
+
+def test_fresnel(oracle):  # :140-195
+    n = 1.5
+    rs, rp, ts, tp = oracle.fresnel_coefficients(0.0, n)
+    assert approx(rs.real, (1 - n) / (1 + n)) and approx(rs.real, rp.real)
+    assert approx(tp.real, 2 / (1 + n)) and approx(tp.real, ts.real)
+    rs, rp, ts, tp = oracle.fresnel_coefficients(math.atan(n), n)
+    # runtests.jl:157 asserts `real(rp) ≈ 0` (exact zero).  Whether the 1-ulp cancellation lands on 0 depends on the
+    # libm (Julia's pure-Julia sin/cos use muladd and are not bit-identical to glibc's): here it is 1 ulp of 1.25.
+    assert abs(rp.real) <= 2.3e-16
+    rs, rp, ts, tp = oracle.fresnel_coefficients(math.pi / 2, n)
+    assert approx(rs.real, -1) and approx(rp.real, 1) and approx(ts.real, 0, atol=1e-300) or abs(ts.real) == 0
+    assert abs(tp.real) <= 2e-16
+    n = 1 / 1.5
+    rs, rp, ts, tp = oracle.fresnel_coefficients(0.0, n)
+    assert approx(rs.real, (1 - n) / (1 + n)) and approx(rs.real, rp.real)
+    assert approx(tp.real, 2 / (1 + n)) and approx(tp.real, ts.real)
+    rs, rp, ts, tp = oracle.fresnel_coefficients(math.atan(n), n)
+    assert abs(rp.real) <= 2e-16
+    rs, rp, ts, tp = oracle.fresnel_coefficients(math.asin(n), n)
+    assert abs(abs(rs) ** 2 - 1) <= 1e-6 and abs(abs(rp) ** 2 - 1) <= 1e-6  # is_internally_reflected
+    assert approx(rs.real, 1) and approx(rp.real, -1) and approx(ts.real, 2) and abs(tp.real - 3) <= 1e-15
+
+
+# ------------------------------------------------------------------ mesh (runtests.jl:819-874)
+def test_moeller_trumbore(oracle):  # :819-829
+    t = 5
+    face = [[1, 1, t], [-1, 1, t], [0, -1, t]]
+    assert approx(oracle.moeller_trumbore(face, [0.0, 0, 0], [0.0, 0, 1]), t)
+
+
+def test_mesh_intersect_rotating_cube(oracle):  # :836-855
+    cube = bmo.CubeMesh(1)
+    bmo.translate3d(cube, -0.5 * np.ones(3))
+    cube.set_new_origin3d()
+    l = []
+    for _ in range(360):
+        sc = scene_of([bmo.Mirror(cube)])
+        t, n = oracle.intersect_shape(sc, cube, np.zeros(3), [1.0, 0, 0])
+        l.append(t)
+        bmo.zrotate3d(cube, math.radians(1))
+    l = np.array(l)
+    assert all(approx(x, 0.5) for x in l[0::90])
+    assert all(approx(x, math.sqrt(2) / 2) for x in l[45::90])
+
+
+def test_mesh_intersect_offset_cube(oracle):  # :857-874
+    t, s = 5, 1
+    cube = bmo.CubeMesh(2 * s)
+    bmo.translate3d(cube, [-s, -s, -s])
+    cube.set_new_origin3d()
+    bmo.translate3d(cube, [t + s, 0, 0])
+    sc = scene_of([bmo.Mirror(cube)])
+    for z in np.arange(-s, s + 1e-12, s / 10):
+        ray = bmo.Ray([0, 0, 0], [t, 0, z])
+        tt, n = oracle.intersect_shape(sc, cube, ray.pos, ray.dir)
+        assert approx(tt, math.sqrt(t ** 2 + z ** 2))
+
+
+def test_mesh_constructors():  # :876-914
+    rfm = bmo.RectangularFlatMesh(2.0, 1)
+    assert np.array_equal(rfm.vertices, [[1, 0, 0.5], [1, 0, -0.5], [-1, 0, -0.5], [-1, 0, 0.5]])
+    assert np.array_equal(rfm.normal3d(0), [0, 1, 0])
+    qfm = bmo.QuadraticFlatMesh(4.0)
+    assert np.array_equal(qfm.vertices, [[2, 0, 2], [2, 0, -2], [-2, 0, -2], [-2, 0, 2]])
+    cm = bmo.CircularFlatMesh(1.0, 4)
+    assert approx(cm.vertices[0], np.zeros(3), atol=1e-15) and approx(cm.vertices[1], [1, 0, 0]) and approx(cm.vertices[2], [0, 0, 1])
+    assert approx(cm.vertices[3], [-1, 0, 0]) and approx(cm.vertices[4], [0, 0, -1])
+    assert np.array_equal(cm.faces[:, 0], [0, 0, 0, 0]) and np.array_equal(cm.faces[:, 1], [1, 2, 3, 4])
+    assert np.array_equal(cm.faces[:, 2], [2, 3, 4, 1])
+    for i in range(4):
+        assert approx(cm.normal3d(i), [0, -1, 0])
+
+
+# ------------------------------------------------------------------ SDFs (runtests.jl:949-989)
+def test_point_sdf_transform(oracle):  # :949-959
+    pt = bmo.TestPointSDF()
+    t, th = 10, math.radians(30)
+    bmo.translate3d(pt, [t, 0, 0])
+    bmo.rotate3d(pt, [0, 1, 0], th)
+    local = pt.tdir @ (np.zeros(3) - pt.pos)
+    assert approx(local[0], -t * math.cos(th)) and abs(local[1]) < 1e-15 and approx(local[2], -t * math.sin(th))
+
+
+def test_point_sdf_intersect(oracle):  # :961-977
+    t = 10.0
+    pt = bmo.TestPointSDF()
+    bmo.translate3d(pt, [t, 0, 0])
+    sc = scene_of([bmo.IntersectableObject(pt)])
+    r1, r2, r3 = bmo.Ray(np.zeros(3), [1.0, 0, 0]), bmo.Ray(np.zeros(3), [1.0, 1, 0]), bmo.Ray(np.zeros(3), [1.0, 0, 1])
+    i1 = oracle.intersect_shape(sc, pt, r1.pos, r1.dir)
+    assert i1[0] == t  # `length(i1) == t` exact
+    assert oracle.intersect_shape(sc, pt, r2.pos, r2.dir) is None
+    assert oracle.intersect_shape(sc, pt, r3.pos, r3.dir) is None
+    # the miss shortcut of the engine must not be needed for the oracle: cull disabled gives the same
+    sc2 = scene_of([bmo.IntersectableObject(pt)], cull=False)
+    assert oracle.intersect_shape(sc2, pt, r2.pos, r2.dir) is None
+
+
+def test_point_sdf_normals(oracle):  # :979-989 exact equality
+    pt = bmo.TestPointSDF()
+    off = np.array([5.0, 0, 0])
+    bmo.translate3d(pt, off)
+    sc = scene_of([bmo.IntersectableObject(pt)])
+    for p in ([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]):
+        assert np.array_equal(oracle.normal3d(sc, pt, np.array(p) + off), p)
+
+
+# ------------------------------------------------------------------ System (runtests.jl:1013-1080)
+def _multipass():
+    n_mirrors, radius = 101, 1
+    L = 6 * radius / n_mirrors
+    dth = 360 / (n_mirrors + 1)
+    mirrors = [bmo.SquarePlanoMirror2D(L) for _ in range(n_mirrors)]
+    th = dth
+    for m in mirrors:
+        point = radius * np.array([math.cos(math.radians(th)), math.sin(math.radians(th)), 0])
+        bmo.zrotate3d(m, math.radians(th))
+        bmo.translate3d(m, point)
+        th += dth
+    for m in mirrors:
+        bmo.zrotate3d(m, math.radians(90))
+    d = bmo.rotation_matrix([0, 0, 1], math.radians(dth)) @ np.array([-1.0, 0, 0])
+    origin = np.array([radius, 0, 0]) - d
+    return mirrors, origin, d, dth, n_mirrors
+
+
+def test_trace_all_identity(oracle):  # :1030-1045
+    mirrors, origin, d, dth, n = _multipass()
+    sc = scene_of(mirrors)
+    ray = bmo.Ray(origin, d)
+    first = (n + 1) // 2 + 2 - 1  # 0-based
+    hits = [(oracle.intersect_object(sc, i, ray.pos, ray.dir), i) for i in range(n)]
+    hits = [(h[0], i) for h, i in hits if h is not None]
+    assert min(hits)[1] == first
+    beam = bmo.Beam(bmo.Ray(origin, d))
+    oracle.solve_system(bmo.System(mirrors), beam, r_max=2)
+    assert beam.rays[0].intersection.object is mirrors[first]
+
+
+def test_multipass_cell(oracle):  # :1047-1062
+    mirrors, origin, d, dth, n = _multipass()
+    system = bmo.System(mirrors)
+    beam = bmo.Beam(bmo.Ray(origin, d))
+    oracle.solve_system(system, beam, r_max=10)
+    assert len(beam.rays) == 10
+    assert beam.rays[-1].intersection is None  # pushed but never traced (System.jl:133)
+    beam = bmo.Beam(bmo.Ray(origin, d))
+    oracle.solve_system(system, beam, r_max=1000000)
+    assert len(beam.rays) == n + 1
+    first, last = beam.rays[0].dir, beam.rays[-1].dir
+    assert approx(180 - math.degrees(angle3d(first, last)), 2 * dth)
+    assert beam.rays[0].intersection.object is mirrors[(n + 1) // 2 + 2 - 1]
+
+
+# ------------------------------------------------------------------ lenses (runtests.jl:1195-1321)
+def line_point_distance3d(pos, dir, point):
+    return np.linalg.norm(np.cross(pos - point, dir)) / np.linalg.norm(dir)
+
+
+def test_thin_lens_focal_length(oracle):  # :1195-1224
+    R1 = R2 = 1
+    nl = 1.5
+    tl = bmo.ThinLensSDF(R1, R2, 0.1)
+    bmo.translate3d(tl, [0, -tl.thickness / 2, 0])
+    system = bmo.System([bmo.Lens(tl, lambda x: 1.5)])
+    f_ana = 1 / ((nl - 1) * (1 / R1 - 1 / (-R2)))
+    for z in np.arange(-0.04, 0.04 + 1e-12, 0.01):
+        if abs(z) < 1e-12:
+            continue
+        beam = bmo.Beam(bmo.Ray([0, -0.5, z], [0, 1, 0], 1e3))
+        oracle.solve_system(system, beam)
+        xs = np.arange(0.1, 1.5 + 1e-12, 0.1)
+        df = [line_point_distance3d(beam.rays[-1].pos, beam.rays[-1].dir, np.array([0, x, 0])) for x in xs]
+        assert approx(xs[int(np.argmin(df))], f_ana)
+
+
+def test_lens_constructor_thickness():  # :1226-1258  (exact ==)
+    for r1, r2, l in ((34.9e-3, -34.9e-3, 6.8e-3), (math.inf, -15.5e-3, 8.6e-3), (-52.0e-3, 52.0e-3, 3e-3), (math.inf, 25.7e-3, 3.5e-3),
+                      (-82.2e-3, -32.1e-3, 3.6e-3)):
+        lens = bmo.SphericalLens(r1, r2, l)
+        assert isinstance(lens.shape, (bmo.UnionSDF,))
+        assert bmo.thickness(lens.shape) == l
+
+
+@pytest.mark.parametrize("lam,bfl,df", [(488e-9, 143.68e-3, -2.064e-4), (707e-9, 143.68e-3, 0.0), (1064e-9, 143.68e-3, 7.466e-4)])
+def test_doublet(oracle, lam, bfl, df):  # :1273-1321
+    lams = [488e-9, 707e-9, 1064e-9]
+    NLAK22 = bmo.DiscreteRefractiveIndex(lams, [1.6591, 1.6456, 1.6374])
+    NSF10 = bmo.DiscreteRefractiveIndex(lams, [1.7460, 1.7168, 1.7021])
+    dl = bmo.SphericalDoubletLens(87.9e-3, -105.6e-3, math.inf, 6e-3, 3e-3, bmo.inch, NLAK22, NSF10)
+    bmo.translate3d(dl, [0.05, 0.05, 0.05])
+    bmo.xrotate3d(dl, math.radians(-60))
+    bmo.zrotate3d(dl, math.radians(45))
+    system = bmo.System([dl])
+    z0 = 5e-3
+    zs = np.linspace(-z0, z0, 30)
+    d = -dl.back.shape.dir[:, 1]
+    pos = dl.front.shape.pos + 0.05 * d
+    nv = bmo.linalg.perpendicular(d)
+    f_z = dl.thickness + bfl + df
+    f0 = dl.front.shape.pos + f_z * -d
+    beams = [bmo.Beam(pos + z * nv, -d, lam) for z in zs]
+    oracle.solve_system(system, beams, threads=8)
+    for beam in beams:
+        assert len(beam.rays) == 4
+        assert [r.n for r in beam.rays] == [1, NLAK22(lam), NSF10(lam), 1]
+        ray = beam.rays[-1]
+        t = np.dot(f0 - ray.pos, d) / np.dot(d, ray.dir)  # intersect3d(plane) AbstractRay.jl:162-171
+        p0 = ray.pos + t * ray.dir
+        assert np.linalg.norm(p0 - f0) <= 1e-6
+    # Centre-ray normals (runtests.jl:1309-1314: |n . dir| ≈ 1).  On the ROTATED doublet the exact-axis ray ends on the
+    # degenerate apex of the cemented ConcaveSphericalSurfaceSDF where sdf ~ |y| has a kink: the dual gradient is NaN
+    # (sqrt'(0)) and the central-difference fallback (AbstractSDF.jl:81-88) cancels to rounding noise, so the reference's
+    # own result there depends on last-bit noise of its kinematics and cannot be pinned (the same holds within
+    # rho < sqrt(2 R h) ~ 45 um of the axis, where the h = 1e-8 stencil straddles the kink).  We pin the assertion
+    # 100 um off axis on the rotated lens, and exactly on axis on the un-rotated lens.
+    beam = bmo.Beam(pos + 1e-4 * nv, -d, lam)
+    oracle.solve_system(system, beam)
+    assert len(beam.rays) == 4
+    for r in beam.rays[:-1]:
+        assert abs(abs(np.dot(r.intersection.n, r.dir)) - 1) < 1e-5
+    dl0 = bmo.SphericalDoubletLens(87.9e-3, -105.6e-3, math.inf, 6e-3, 3e-3, bmo.inch, NLAK22, NSF10)
+    beam = bmo.Beam([0, -0.05, 0], [0, 1.0, 0], lam)
+    oracle.solve_system(bmo.System([dl0]), beam)
+    assert len(beam.rays) == 4
+    for r in beam.rays[:-1]:
+        assert approx(abs(np.dot(r.intersection.n, r.dir)), 1)
+
+
+# ------------------------------------------------------------------ surfaces (runtests.jl:1324-1420)
+def working_distance(oracle, lens, offset_z):
+    beam = bmo.Beam(bmo.Ray([0.0, -1.0, offset_z], [0.0, 1.0, 0]))
+    oracle.solve_system(bmo.System([lens]), beam)
+    r = beam.rays[-1]
+    dist = -r.pos[2] / r.dir[2]
+    alpha = math.degrees(math.asin(r.dir[2]))
+    return math.cos(math.radians(alpha)) * dist
+
+
+def test_lens_from_surfaces(oracle):  # :1338-1375
+    d = 25.4e-3
+    lens = bmo.Lens(bmo.SphericalSurface(16.1e-3, d), 8.2e-3, lambda n: 1.458)
+    assert approx(lens.thickness, 8.2e-3)
+    assert abs(bmo.thickness(lens.shape.sdfs[0]) - 2e-3) <= 1e-4
+    assert abs(working_distance(oracle, lens, 0.05 * d / 2) - 29.5e-3) <= 1e-4
+    lens = bmo.Lens(bmo.SphericalSurface(24.5e-3, d), bmo.SphericalSurface(-24.5e-3, d), 9.0e-3, lambda n: 1.517)
+    assert approx(lens.thickness, 9.0e-3)
+    assert abs(bmo.thickness(lens.shape.sdfs[0]) - 1.9e-3) <= 1e-4
+    assert abs(working_distance(oracle, lens, 0.05 * d / 2) - 22.2e-3) <= 1e-3
+    lens = bmo.Lens(bmo.SphericalSurface(math.inf, d), bmo.SphericalSurface(25.7e-3, d), 3.5e-3, lambda n: 1.517)
+    assert approx(lens.thickness, 3.5e-3)
+    assert abs(lens.shape.sdfs[1].sag + bmo.thickness(lens.shape.sdfs[0]) - 0.006858) <= 1e-4
