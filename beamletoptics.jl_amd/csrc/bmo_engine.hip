@@ -1,0 +1,952 @@
+// bmo_engine.hip — MI355X (gfx950) trace engine behind the C ABI of include/bmo.h.
+//
+// Execution model: bounce-synchronous wavefront tracing.
+//   * One launch of step_kernel advances every ACTIVE beam node by one bounce
+//     (tracing_step! + interact3d, System.jl:133-152).  Lane j works on record j of the
+//     current step chunk; the segment log IS the sequence of step chunks (SoA planes), so a
+//     bounce reads the 64 B it needs (pos, dir, n, hint) and writes intersection + next
+//     segment once — SURVEY.md §8d's 184 B/bounce.
+//   * The scene tables (objects, shapes, triangles, n(lambda)) are staged into LDS by every
+//     workgroup; rays stay in HBM as structure-of-arrays planes (coalesced 8 B/lane loads).
+//   * Survivors and beam-splitter children are compacted into the next chunk with a wave
+//     ballot + prefix popcount and ONE atomic per wave (child node ids likewise).
+//   * After the last step, nodes are put in the reference's order (bundle order x BFS order)
+//     by a radix sort on (root, depth, path) keys, and detector hits are compacted in that
+//     order (scan + gather) so the hit buffers equal the reference's push! order.
+// No CPU fallback: every entry point that traces requires a HIP device.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <unistd.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bmo_lane.hpp"
+
+using namespace bmo;
+
+namespace {
+
+thread_local std::string g_err;
+bool dbg_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("BMO_DEBUG") ? 1 : 0;
+    return v == 1;
+}
+#define DBG(...)                          \
+    do {                                  \
+        if (dbg_on()) {                   \
+            fprintf(stderr, "[bmo] " __VA_ARGS__); \
+            fprintf(stderr, "\n");        \
+            fflush(stderr);               \
+        }                                 \
+    } while (0)
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? BMO_ERR_OOM : BMO_ERR_NO_DEVICE,                      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+        }                                                                                                \
+    } while (0)
+
+// ------------------------------------------------------------------ scene blob (LDS image)
+struct BlobHeader {
+    int32_t n_objects, n_shapes, n_children, n_tris, n_media, n_lambda, n_detectors, march_iters;
+    double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
+    uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
+    uint32_t has_splitter, pad;
+};
+
+__host__ __device__ inline SceneView view_of(const char* blob) {
+    const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+    SceneView S;
+    S.objects = reinterpret_cast<const bmo_object*>(blob + h->off_objects);
+    S.shapes = reinterpret_cast<const bmo_shape*>(blob + h->off_shapes);
+    S.children = reinterpret_cast<const int32_t*>(blob + h->off_children);
+    S.tris = reinterpret_cast<const double*>(blob + h->off_tris);
+    S.n_table = reinterpret_cast<const double*>(blob + h->off_ntable);
+    S.n_objects = h->n_objects;
+    S.n_lambda = h->n_lambda;
+    S.eps_srf = h->eps_srf;
+    S.eps_ray = h->eps_ray;
+    S.eps_ins = h->eps_ins;
+    S.mt_keps = h->mt_keps;
+    S.mt_leps = h->mt_leps;
+    S.grad_h = h->grad_h;
+    S.march_iters = h->march_iters;
+    return S;
+}
+
+// ------------------------------------------------------------------ record layout
+// double planes per record: ABI planes first (include/bmo.h), then accumulators
+//   RAY:       0-6 px py pz dx dy dz n | 7-10 t nx ny nz | 11 opl_acc
+//   POLARIZED: 0-10 as RAY | 11-16 Re/Im E0 | 17 opl_acc
+// int planes: 0 node, 1 k, 2 hint_obj, 3 hint_shape, 4 obj, 5 shape, 6 flags
+template <int KIND>
+struct Layout;
+template <>
+struct Layout<BMO_BEAM_RAY> {
+    static constexpr int ABI = 11, ND = 12, OPL = 11;
+};
+template <>
+struct Layout<BMO_BEAM_POLARIZED> {
+    static constexpr int ABI = 17, ND = 18, OPL = 17;
+};
+constexpr int NI = 7;
+enum { I_NODE = 0, I_K = 1, I_HOBJ = 2, I_HSHAPE = 3, I_OBJ = 4, I_SHAPE = 5, I_FLAGS = 6 };
+enum { F_DEAD = 1 };
+
+struct Chunk {
+    double* d;   // [ND][cap]
+    int32_t* i;  // [NI][cap]
+    int64_t cap;
+    int64_t count;
+};
+
+struct Counters {  // device-resident, one per trace
+    unsigned long long next_count;
+    unsigned long long node_count;
+    unsigned long long calls;
+    unsigned long long overflow;
+};
+
+struct NodeArrays {
+    int32_t* root;
+    int32_t* parent;
+    int32_t* nseg;
+    int32_t* status;
+    int32_t* li;
+    int32_t* hit_det;
+    unsigned long long* key;  // root<<32 | depth<<26 | path
+    double* lambda;
+    double* hit;  // [cap][9]
+    int64_t cap;
+};
+
+struct StepParams {
+    const char* blob;
+    uint32_t blob_bytes;
+    int32_t use_lds;
+    Chunk cur, nxt;
+    Counters* ctr;
+    NodeArrays nodes;
+    int32_t r_max;
+};
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ inline int prefix_rank(unsigned long long mask) {
+    return __popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void step_kernel(StepParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const char* blob = P.blob;
+    if (P.use_lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(P.blob);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
+        __syncthreads();
+        blob = lds;
+    }
+    SceneView S = view_of(blob);
+    using L = Layout<KIND>;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = P.cur.count, cap = P.cur.cap;
+    const bool valid = j < m;
+
+    bool survive = false, split = false;
+    int32_t node = -1, k = 0, li = 0;
+    StepOut o;
+    o.outcome = OUT_MISS;
+    o.status = 0;
+    o.hint_obj = o.hint_shape = -1;
+    o.det_slot = -1;
+    uint32_t calls = 0;
+    double opl_next = 0.0, lambda = 0.0;
+
+    if (valid) {
+        const double* D = P.cur.d;
+        int32_t* I = P.cur.i;
+        node = I[I_NODE * cap + j];
+        k = I[I_K * cap + j];
+        const int32_t flags = I[I_FLAGS * cap + j];
+        RayS ray;
+        ray.pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
+        ray.dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+        ray.n = D[6 * cap + j];
+        if (KIND == BMO_BEAM_POLARIZED)
+            for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
+        const double opl_acc = D[L::OPL * cap + j];
+        li = P.nodes.li[node];
+        lambda = P.nodes.lambda[node];
+        Hit X;
+        X.shape = -1;
+        X.obj = -1;
+        X.t = kinf();
+        X.n = {0, 0, 0};
+        int status = 0;
+        if (flags & F_DEAD) {
+            status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
+        } else {
+            X = tracing_step(S, ray.pos, ray.dir, I[I_HOBJ * cap + j], I[I_HSHAPE * cap + j], calls);
+            if (X.shape < 0) {
+                status = BMO_NODE_MISS;
+            } else {
+                interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
+                status = o.status;
+                if (o.outcome == OUT_CONTINUE) {
+                    survive = true;
+                    opl_next = opl_acc + X.t * ray.n;
+                } else if (o.outcome == OUT_SPLIT) {
+                    split = true;
+                    status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                    opl_next = opl_acc + X.t * ray.n;
+                } else {
+                    status |= BMO_NODE_STOPPED;
+                }
+            }
+        }
+        // intersection part of this record
+        double* Dw = P.cur.d;
+        Dw[7 * cap + j] = X.t;
+        Dw[8 * cap + j] = X.n.x;
+        Dw[9 * cap + j] = X.n.y;
+        Dw[10 * cap + j] = X.n.z;
+        I[I_OBJ * cap + j] = X.obj;
+        I[I_SHAPE * cap + j] = X.shape;
+        if (!survive) {  // node ends here
+            P.nodes.nseg[node] = k + 1;
+            P.nodes.status[node] = status;
+            if (o.det_slot >= 0) {
+                P.nodes.hit_det[node] = o.det_slot;
+                for (int c = 0; c < 9; ++c) P.nodes.hit[(int64_t)node * 9 + c] = o.det[c];
+            }
+        }
+    }
+
+    // ---- wave-level compaction: survivors first, then 2 children per splitting lane
+    const unsigned long long m_surv = __ballot(survive);
+    const unsigned long long m_split = __ballot(split);
+    const int n_surv = __popcll(m_surv), n_split = __popcll(m_split);
+    unsigned long long base = 0, nbase = 0;
+    if (n_surv + n_split > 0) {
+        if (lane_id() == 0) {
+            base = atomicAdd(&P.ctr->next_count, (unsigned long long)(n_surv + 2 * n_split));
+            if (n_split) nbase = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * n_split));
+        }
+        base = __shfl(base, 0);
+        nbase = __shfl(nbase, 0);
+    }
+    const int64_t ncap = P.nxt.cap;
+    auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
+        if (slot >= ncap) {
+            atomicAdd(&P.ctr->overflow, 1ull);
+            return;
+        }
+        double* D = P.nxt.d;
+        int32_t* I = P.nxt.i;
+        D[0 * ncap + slot] = r.pos.x;
+        D[1 * ncap + slot] = r.pos.y;
+        D[2 * ncap + slot] = r.pos.z;
+        D[3 * ncap + slot] = r.dir.x;
+        D[4 * ncap + slot] = r.dir.y;
+        D[5 * ncap + slot] = r.dir.z;
+        D[6 * ncap + slot] = r.n;
+        if (KIND == BMO_BEAM_POLARIZED)
+            for (int c = 0; c < 3; ++c) {
+                D[(11 + 2 * c) * ncap + slot] = r.E0[c].re;
+                D[(12 + 2 * c) * ncap + slot] = r.E0[c].im;
+            }
+        D[L::OPL * ncap + slot] = opl;
+        I[I_NODE * ncap + slot] = nd;
+        I[I_K * ncap + slot] = kk;
+        I[I_HOBJ * ncap + slot] = ho;
+        I[I_HSHAPE * ncap + slot] = hs;
+        I[I_FLAGS * ncap + slot] = fl;
+    };
+    if (survive) {
+        const int64_t slot = (int64_t)base + prefix_rank(m_surv);
+        const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+        write_next(slot, o.next, node, k + 1, o.hint_obj, o.hint_shape, fl, opl_next);
+    }
+    if (split) {
+        const int r = prefix_rank(m_split);
+        const int64_t slot = (int64_t)base + n_surv + 2 * r;
+        const int64_t cn = (int64_t)nbase + 2 * r;
+        if (cn + 1 < P.nodes.cap) {
+            const unsigned long long pkey = P.nodes.key[node];
+            const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+            for (int w = 0; w < 2; ++w) {
+                const int64_t c = cn + w;
+                P.nodes.root[c] = (int32_t)root;
+                P.nodes.parent[c] = node;
+                P.nodes.nseg[c] = 1;
+                P.nodes.status[c] = 0;
+                P.nodes.li[c] = li;
+                P.nodes.lambda[c] = lambda;
+                P.nodes.hit_det[c] = -1;
+                P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+            }
+            const int32_t fl = (1 < P.r_max) ? 0 : F_DEAD;
+            write_next(slot, o.next, (int32_t)cn, 0, -1, -1, fl, opl_next);
+            write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, fl, opl_next);
+        } else {
+            atomicAdd(&P.ctr->overflow, 1ull);
+        }
+    }
+    // ---- reference intersect3d call count (BASELINE metric numerator)
+    unsigned int c = calls;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane_id() == 0 && c) atomicAdd(&P.ctr->calls, (unsigned long long)c);
+}
+
+// ------------------------------------------------------------------ small helper kernels
+template <int KIND>
+__global__ void init_roots_kernel(const double* planes, const int32_t* lambda_idx, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max) {
+    using L = Layout<KIND>;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t cap = c0.cap;
+    for (int p = 0; p < 6; ++p) c0.d[p * cap + j] = planes[p * n + j];
+    c0.d[6 * cap + j] = planes[7 * n + j];
+    if (KIND == BMO_BEAM_POLARIZED)
+        for (int p = 0; p < 6; ++p) c0.d[(11 + p) * cap + j] = planes[(8 + p) * n + j];
+    c0.d[L::OPL * cap + j] = 0.0;
+    c0.i[I_NODE * cap + j] = (int32_t)j;
+    c0.i[I_K * cap + j] = 0;
+    c0.i[I_HOBJ * cap + j] = -1;
+    c0.i[I_HSHAPE * cap + j] = -1;
+    c0.i[I_FLAGS * cap + j] = (1 < r_max) ? 0 : F_DEAD;
+    nodes.root[j] = (int32_t)j;
+    nodes.parent[j] = -1;
+    nodes.nseg[j] = 1;
+    nodes.status[j] = 0;
+    nodes.li[j] = lambda_idx[j];
+    nodes.lambda[j] = planes[6 * n + j];
+    nodes.hit_det[j] = -1;
+    nodes.key[j] = ((unsigned long long)j) << 32;
+}
+
+__global__ void iota_kernel(int32_t* a, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) a[j] = (int32_t)j;
+}
+// flags[d*n + i] = 1 if canonical node i recorded a hit on detector d
+__global__ void hit_flags_kernel(const int32_t* order, const int32_t* hit_det, int64_t n, int32_t n_det, int32_t* flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t d = hit_det[order[i]];
+    for (int32_t q = 0; q < n_det; ++q) flags[(int64_t)q * n + i] = (q == d) ? 1 : 0;
+}
+__global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, const double* hit, int64_t n, const int32_t* flags,
+                                  const int32_t* offs, double* out, int32_t* out_node) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t nd = order[i];
+    const int32_t d = hit_det[nd];
+    if (d < 0) return;
+    const int64_t pos = offs[(int64_t)d * n + i];
+    for (int c = 0; c < 9; ++c) out[pos * 9 + c] = hit[(int64_t)nd * 9 + c];
+    out_node[pos] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------ host-side objects
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b) {
+        release();
+        if (b == 0) b = 16;
+        hipError_t e = hipMalloc(&p, b);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(BMO_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+        bytes = b;
+        return BMO_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+}  // namespace
+
+struct bmo_scene {
+    std::vector<char> blob;
+    BlobHeader hdr;
+    std::vector<std::pair<int, std::unique_ptr<DevBuf>>> dev;  // per-device copy of the blob
+    const char* device_blob(int device, int& rc) {
+        for (auto& d : dev)
+            if (d.first == device) return static_cast<const char*>(d.second->p);
+        auto b = std::make_unique<DevBuf>();
+        rc = b->alloc(blob.size());
+        if (rc) return nullptr;
+        if (hipMemcpy(b->p, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(BMO_ERR_NO_DEVICE, "hipMemcpy(scene)");
+            return nullptr;
+        }
+        const char* p = static_cast<const char*>(b->p);
+        dev.emplace_back(device, std::move(b));
+        return p;
+    }
+};
+
+struct bmo_device_batch {
+    int device = 0;
+    int kind = 0;
+    int64_t n = 0;
+    int n_planes = 0;
+    DevBuf planes, li;
+};
+
+struct bmo_trace_result {
+    int device = 0, kind = 0, n_detectors = 0;
+    int64_t n_roots = 0, n_nodes = 0, n_records = 0;
+    unsigned long long calls = 0;
+    int n_steps = 0;
+    double kernel_ms = 0, total_ms = 0;
+    int nd = 0;  // double planes per record (device layout)
+    int abi_planes = 0;
+    // device state
+    std::vector<std::unique_ptr<DevBuf>> arena;  // chunk storage
+    std::vector<Chunk> chunks;
+    DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, order, det_data, det_node;
+    std::vector<int64_t> det_count, det_offset;
+    // host views (filled by bmo_result_view)
+    bool viewed = false;
+    std::vector<int32_t> h_root, h_parent, h_first_child, h_first_rec, h_nseg, h_status, h_rec_obj, h_rec_shape, h_det_node;
+    std::vector<double> h_aux, h_rec, h_det;
+};
+
+namespace {
+
+template <int KIND>
+int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result* R) {
+    using L = Layout<KIND>;
+    const int device = batch->device;
+    HIP_TRY(hipSetDevice(device));
+    int rc = BMO_OK;
+    const char* dblob = scene->device_blob(device, rc);
+    if (rc) return rc;
+    const int64_t n = batch->n;
+    const bool has_split = scene->hdr.has_splitter != 0;
+    R->device = device;
+    R->kind = KIND;
+    R->n_roots = n;
+    R->n_detectors = scene->hdr.n_detectors;
+    R->nd = L::ND;
+    R->abi_planes = L::ABI;
+
+    hipStream_t stream;
+    HIP_TRY(hipStreamCreate(&stream));
+    hipEvent_t ev_a, ev_b, ev_t0, ev_t1;
+    HIP_TRY(hipEventCreate(&ev_a));
+    HIP_TRY(hipEventCreate(&ev_b));
+    HIP_TRY(hipEventCreate(&ev_t0));
+    HIP_TRY(hipEventCreate(&ev_t1));
+    HIP_TRY(hipEventRecord(ev_t0, stream));
+
+    // node arrays: roots + room for children (grown on demand)
+    int64_t node_cap = has_split ? 3 * n + 64 : n;
+    auto alloc_nodes = [&](int64_t cap) -> int {
+        int r;
+        if ((r = R->n_root.alloc(cap * 4))) return r;
+        if ((r = R->n_parent.alloc(cap * 4))) return r;
+        if ((r = R->n_nseg.alloc(cap * 4))) return r;
+        if ((r = R->n_status.alloc(cap * 4))) return r;
+        if ((r = R->n_li.alloc(cap * 4))) return r;
+        if ((r = R->n_hitdet.alloc(cap * 4))) return r;
+        if ((r = R->n_key.alloc(cap * 8))) return r;
+        if ((r = R->n_lambda.alloc(cap * 8))) return r;
+        if ((r = R->n_hit.alloc(cap * 72))) return r;
+        return BMO_OK;
+    };
+    if ((rc = alloc_nodes(node_cap))) return rc;
+    auto node_arrays = [&]() {
+        NodeArrays a;
+        a.root = (int32_t*)R->n_root.p;
+        a.parent = (int32_t*)R->n_parent.p;
+        a.nseg = (int32_t*)R->n_nseg.p;
+        a.status = (int32_t*)R->n_status.p;
+        a.li = (int32_t*)R->n_li.p;
+        a.hit_det = (int32_t*)R->n_hitdet.p;
+        a.key = (unsigned long long*)R->n_key.p;
+        a.lambda = (double*)R->n_lambda.p;
+        a.hit = (double*)R->n_hit.p;
+        a.cap = node_cap;
+        return a;
+    };
+    auto grow_nodes = [&](int64_t need) -> int {
+        if (need <= node_cap) return BMO_OK;
+        int64_t ncap = std::max(need, node_cap * 2);
+        auto mv = [&](DevBuf& b, size_t elem) -> int {
+            DevBuf nb;
+            int r = nb.alloc((size_t)ncap * elem);
+            if (r) return r;
+            if (hipMemcpyAsync(nb.p, b.p, (size_t)node_cap * elem, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return fail(BMO_ERR_NO_DEVICE, "grow nodes");
+            (void)hipStreamSynchronize(stream);
+            std::swap(b.p, nb.p);
+            std::swap(b.bytes, nb.bytes);
+            return BMO_OK;
+        };
+        int r;
+        if ((r = mv(R->n_root, 4)) || (r = mv(R->n_parent, 4)) || (r = mv(R->n_nseg, 4)) || (r = mv(R->n_status, 4)) || (r = mv(R->n_li, 4)) ||
+            (r = mv(R->n_hitdet, 4)) || (r = mv(R->n_key, 8)) || (r = mv(R->n_lambda, 8)) || (r = mv(R->n_hit, 72)))
+            return r;
+        node_cap = ncap;
+        return BMO_OK;
+    };
+
+    // chunk arena: bump allocation out of large blocks
+    const size_t rec_bytes = (size_t)L::ND * 8 + (size_t)NI * 4;
+    size_t block_bytes = std::max<size_t>((size_t)n * rec_bytes * 6, (size_t)1 << 20);
+    size_t top = 0;  // offset in the last block
+    auto new_chunk = [&](int64_t cap, Chunk& c) -> int {
+        cap = std::max<int64_t>(cap, 1);
+        const size_t cap_al = ((size_t)cap + 1) & ~(size_t)1;  // keep int planes 8-byte aligned
+        const size_t need = cap_al * rec_bytes;
+        if (R->arena.empty() || top + need > R->arena.back()->bytes) {
+            auto b = std::make_unique<DevBuf>();
+            int r = b->alloc(std::max(block_bytes, need));
+            if (r) return r;
+            R->arena.push_back(std::move(b));
+            top = 0;
+        }
+        char* base = static_cast<char*>(R->arena.back()->p) + top;
+        c.d = reinterpret_cast<double*>(base);
+        c.i = reinterpret_cast<int32_t*>(base + cap_al * (size_t)L::ND * 8);
+        c.cap = (int64_t)cap_al;
+        c.count = 0;
+        top += need;
+        return BMO_OK;
+    };
+    auto shrink_last = [&](Chunk& c, int64_t used) {
+        // planes are strided by cap, so the chunk keeps its footprint; nothing to return.
+        c.count = used;
+    };
+
+    DevBuf ctr_buf;
+    if ((rc = ctr_buf.alloc(sizeof(Counters)))) return rc;
+    Counters* d_ctr = static_cast<Counters*>(ctr_buf.p);
+    Counters h_ctr{0, (unsigned long long)n, 0, 0};
+    HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, stream));
+
+    Chunk cur;
+    if ((rc = new_chunk(n, cur))) return rc;
+    cur.count = n;
+    if (n > 0) {
+        hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
+                           (const int32_t*)batch->li.p, n, cur, node_arrays(), opts->r_max);
+    }
+    const uint32_t blob_bytes = (uint32_t)scene->blob.size();
+    const int use_lds = (blob_bytes <= 120 * 1024 && !getenv("BMO_NO_LDS")) ? 1 : 0;
+    DBG("roots initialised n=%lld blob=%u use_lds=%d", (long long)n, blob_bytes, use_lds);
+    if (dbg_on()) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        DBG("init kernel done");
+    }
+    const size_t lds_bytes = use_lds ? blob_bytes : 0;
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+
+    int64_t n_nodes = n;
+    double kernel_ms = 0;
+    int steps = 0;
+    while (cur.count > 0) {
+        const int64_t m = cur.count;
+        Chunk nxt;
+        if ((rc = new_chunk(has_split ? 2 * m : m, nxt))) return rc;
+        if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
+        StepParams P;
+        P.blob = dblob;
+        P.blob_bytes = blob_bytes;
+        P.use_lds = use_lds;
+        P.cur = cur;
+        P.nxt = nxt;
+        P.ctr = d_ctr;
+        P.nodes = node_arrays();
+        P.r_max = opts->r_max;
+        DBG("step %d launching m=%lld", steps, (long long)m);
+        HIP_TRY(hipEventRecord(ev_a, stream));
+        hipLaunchKernelGGL((step_kernel<KIND>), dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
+        HIP_TRY(hipEventRecord(ev_b, stream));
+        HIP_TRY(hipMemcpyAsync(&h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_a, ev_b));
+        kernel_ms += ms;
+        DBG("step %d done %.3f ms next=%llu nodes=%llu calls=%llu", steps, ms, h_ctr.next_count, h_ctr.node_count, h_ctr.calls);
+        steps += 1;
+        if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
+        R->chunks.push_back(cur);
+        shrink_last(nxt, (int64_t)h_ctr.next_count);
+        n_nodes = (int64_t)h_ctr.node_count;
+        cur = nxt;
+        // reset next_count for the following step
+        h_ctr.next_count = 0;
+        HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    }
+    R->n_nodes = n_nodes;
+    R->calls = h_ctr.calls;
+    R->n_steps = steps;
+    R->kernel_ms = kernel_ms;
+    int64_t nrec = 0;
+    for (auto& c : R->chunks) nrec += c.count;
+    R->n_records = nrec;
+
+    // ---- canonical node order (bundle order x BFS order): sort by (root, depth, path)
+    if ((rc = R->order.alloc((size_t)std::max<int64_t>(n_nodes, 1) * 4))) return rc;
+    const unsigned nb = (unsigned)((n_nodes + 255) / 256);
+    if (n_nodes > 0) hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, stream, (int32_t*)R->order.p, n_nodes);
+    if (n_nodes > n) {
+        DevBuf keys_out, vals_out, tmp;
+        if ((rc = keys_out.alloc((size_t)n_nodes * 8)) || (rc = vals_out.alloc((size_t)n_nodes * 4))) return rc;
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)R->n_key.p, (unsigned long long*)keys_out.p,
+                                                   (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, 64, stream));
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)R->n_key.p, (unsigned long long*)keys_out.p,
+                                                   (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, 64, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::swap(R->order.p, vals_out.p);
+        std::swap(R->order.bytes, vals_out.bytes);
+    }
+    // ---- detector hits in reference push! order: flags -> exclusive scan -> gather
+    const int nd = R->n_detectors;
+    R->det_count.assign(nd, 0);
+    R->det_offset.assign(nd, 0);
+    if (nd > 0 && n_nodes > 0) {
+        DevBuf flags, offs, tmp;
+        const int64_t tot = (int64_t)nd * n_nodes;
+        if ((rc = flags.alloc((size_t)tot * 4)) || (rc = offs.alloc((size_t)tot * 4))) return rc;
+        hipLaunchKernelGGL(hit_flags_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p, n_nodes, nd,
+                           (int32_t*)flags.p);
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
+        // per-detector offsets = scan value at the start of each detector's segment; total = last offs + last flag
+        std::vector<int32_t> h_off(nd + 1, 0);
+        for (int d = 0; d < nd; ++d)
+            HIP_TRY(hipMemcpyAsync(&h_off[d], (const int32_t*)offs.p + (int64_t)d * n_nodes, 4, hipMemcpyDeviceToHost, stream));
+        int32_t last_off = 0, last_flag = 0;
+        HIP_TRY(hipMemcpyAsync(&last_off, (const int32_t*)offs.p + tot - 1, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&last_flag, (const int32_t*)flags.p + tot - 1, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        h_off[nd] = last_off + last_flag;
+        const int64_t total = h_off[nd];
+        for (int d = 0; d < nd; ++d) {
+            R->det_offset[d] = h_off[d];
+            R->det_count[d] = h_off[d + 1] - h_off[d];
+        }
+        if ((rc = R->det_data.alloc((size_t)std::max<int64_t>(total, 1) * 72)) || (rc = R->det_node.alloc((size_t)std::max<int64_t>(total, 1) * 4)))
+            return rc;
+        hipLaunchKernelGGL(hit_gather_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
+                           (const double*)R->n_hit.p, n_nodes, (const int32_t*)flags.p, (const int32_t*)offs.p, (double*)R->det_data.p,
+                           (int32_t*)R->det_node.p);
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    HIP_TRY(hipEventRecord(ev_t1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float tms = 0;
+    HIP_TRY(hipEventElapsedTime(&tms, ev_t0, ev_t1));
+    R->total_ms = tms;
+    (void)hipEventDestroy(ev_a);
+    (void)hipEventDestroy(ev_b);
+    (void)hipEventDestroy(ev_t0);
+    (void)hipEventDestroy(ev_t1);
+    (void)hipStreamDestroy(stream);
+    return BMO_OK;
+}
+
+template <class T>
+int dl(std::vector<T>& h, const void* d, size_t count) {
+    h.resize(count);
+    if (count == 0) return BMO_OK;
+    if (hipMemcpy(h.data(), d, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return fail(BMO_ERR_NO_DEVICE, "hipMemcpy D2H");
+    return BMO_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int bmo_version(void) { return BMO_ABI_VERSION; }
+const char* bmo_last_error(void) { return g_err.c_str(); }
+
+int bmo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
+    if (!d || !out) return fail(BMO_ERR_INVALID, "null argument");
+    if (d->abi_version != BMO_ABI_VERSION) return fail(BMO_ERR_INVALID, "abi version mismatch");
+    if (d->n_objects < 0 || d->n_shapes < 0 || d->n_lambda < 1) return fail(BMO_ERR_INVALID, "bad counts");
+    for (int i = 0; i < d->n_shapes; ++i) {
+        const bmo_shape& s = d->shapes[i];
+        if (s.kind < 0 || s.kind >= BMO_SHAPE_KIND_COUNT) return fail(BMO_ERR_UNSUPPORTED, "unknown shape kind");
+        if (s.kind == BMO_SHAPE_UNION || s.kind == BMO_SHAPE_MENISCUS) {
+            if (s.child_begin < 0 || s.child_begin + s.child_count > d->n_children || s.child_count < 1)
+                return fail(BMO_ERR_INVALID, "child range out of bounds");
+            if (s.kind == BMO_SHAPE_MENISCUS && s.child_count != 3) return fail(BMO_ERR_INVALID, "meniscus needs 3 children");
+            for (int c = 0; c < s.child_count; ++c) {
+                int ch = d->children[s.child_begin + c];
+                if (ch < 0 || ch >= d->n_shapes) return fail(BMO_ERR_INVALID, "child id out of bounds");
+                int ck = d->shapes[ch].kind;
+                if (ck == BMO_SHAPE_UNION || ck == BMO_SHAPE_MESH) return fail(BMO_ERR_INVALID, "nested union / mesh child");
+                if (s.kind == BMO_SHAPE_MENISCUS && ck == BMO_SHAPE_MENISCUS) return fail(BMO_ERR_INVALID, "nested meniscus");
+            }
+        }
+        if (s.kind == BMO_SHAPE_MESH && (s.tri_begin < 0 || s.tri_begin + s.tri_count > d->n_tris))
+            return fail(BMO_ERR_INVALID, "triangle range out of bounds");
+    }
+    bool has_split = false;
+    for (int i = 0; i < d->n_objects; ++i) {
+        const bmo_object& o = d->objects[i];
+        if (o.kind < 0 || o.kind >= BMO_OBJ_KIND_COUNT) return fail(BMO_ERR_UNSUPPORTED, "unknown object kind");
+        int np = (o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_PLATE_BS) ? 2 : (o.kind == BMO_OBJ_CUBE_BS ? 3 : 1);
+        for (int k = 0; k < np; ++k)
+            if (o.shape[k] < 0 || o.shape[k] >= d->n_shapes) return fail(BMO_ERR_INVALID, "object shape id out of bounds");
+        for (int k = 0; k < 2; ++k)
+            if (o.medium[k] >= d->n_media) return fail(BMO_ERR_INVALID, "medium id out of bounds");
+        if ((o.kind == BMO_OBJ_REFRACTIVE || o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_PLATE_BS || o.kind == BMO_OBJ_CUBE_BS) && o.medium[0] < 0)
+            return fail(BMO_ERR_INVALID, "refractive object without medium");
+        if ((o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_CUBE_BS) && o.medium[1] < 0) return fail(BMO_ERR_INVALID, "missing second medium");
+        if ((o.kind == BMO_OBJ_SPOTDETECTOR || o.kind == BMO_OBJ_PSFDETECTOR) && (o.detector < 0 || o.detector >= d->n_detectors))
+            return fail(BMO_ERR_INVALID, "detector slot out of bounds");
+        if (o.kind == BMO_OBJ_THIN_BS || o.kind == BMO_OBJ_PLATE_BS || o.kind == BMO_OBJ_CUBE_BS) has_split = true;
+    }
+    auto sc = std::make_unique<bmo_scene>();
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    BlobHeader h{};
+    h.n_objects = d->n_objects;
+    h.n_shapes = d->n_shapes;
+    h.n_children = d->n_children;
+    h.n_tris = d->n_tris;
+    h.n_media = d->n_media;
+    h.n_lambda = d->n_lambda;
+    h.n_detectors = d->n_detectors;
+    h.march_iters = d->march_iters;
+    h.eps_srf = d->eps_srf;
+    h.eps_ray = d->eps_ray;
+    h.eps_ins = d->eps_ins;
+    h.mt_keps = d->mt_keps;
+    h.mt_leps = d->mt_leps;
+    h.grad_h = d->grad_h;
+    h.has_splitter = has_split ? 1 : 0;
+    size_t off = al(sizeof(BlobHeader));
+    h.off_objects = (uint32_t)off;
+    off = al(off + sizeof(bmo_object) * (size_t)d->n_objects);
+    h.off_shapes = (uint32_t)off;
+    off = al(off + sizeof(bmo_shape) * (size_t)d->n_shapes);
+    h.off_children = (uint32_t)off;
+    off = al(off + 4 * (size_t)d->n_children);
+    h.off_tris = (uint32_t)off;
+    off = al(off + 72 * (size_t)d->n_tris);
+    h.off_ntable = (uint32_t)off;
+    off = al(off + 8 * (size_t)std::max(1, d->n_media) * (size_t)d->n_lambda);
+    h.total = (uint32_t)off;
+    sc->blob.assign(off, 0);
+    std::memcpy(sc->blob.data(), &h, sizeof h);
+    if (d->n_objects) std::memcpy(sc->blob.data() + h.off_objects, d->objects, sizeof(bmo_object) * (size_t)d->n_objects);
+    if (d->n_shapes) std::memcpy(sc->blob.data() + h.off_shapes, d->shapes, sizeof(bmo_shape) * (size_t)d->n_shapes);
+    if (d->n_children) std::memcpy(sc->blob.data() + h.off_children, d->children, 4 * (size_t)d->n_children);
+    if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
+    if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
+    sc->hdr = h;
+    *out = sc.release();
+    return BMO_OK;
+}
+
+int bmo_scene_destroy(bmo_scene* s) {
+    delete s;
+    return BMO_OK;
+}
+
+int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, bmo_device_batch** out) {
+    if (!scene || !in || !out) return fail(BMO_ERR_INVALID, "null argument");
+    if (in->kind != BMO_BEAM_RAY && in->kind != BMO_BEAM_POLARIZED && in->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bad beam kind");
+    const int want = in->kind == BMO_BEAM_RAY ? BMO_PLANES_RAY : (in->kind == BMO_BEAM_POLARIZED ? BMO_PLANES_POLARIZED : BMO_PLANES_GAUSSIAN);
+    if (in->n_planes != want || in->n < 0) return fail(BMO_ERR_INVALID, "bad plane count");
+    if (in->kind == BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_UNSUPPORTED, "GaussianBeamlet tracing is not built yet");
+    if (in->n > 0x7fffffff / 4) return fail(BMO_ERR_INVALID, "batch too large for one device (shard it)");
+    for (int64_t i = 0; i < in->n; ++i)
+        if (in->lambda_idx[i] < 0 || in->lambda_idx[i] >= scene->hdr.n_lambda) return fail(BMO_ERR_INVALID, "lambda_idx out of range");
+    int ndev = bmo_device_count();
+    if (ndev <= 0) return fail(BMO_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(BMO_ERR_INVALID, "bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    auto b = std::make_unique<bmo_device_batch>();
+    b->device = device;
+    b->kind = in->kind;
+    b->n = in->n;
+    b->n_planes = in->n_planes;
+    int rc;
+    if ((rc = b->planes.alloc((size_t)in->n * in->n_planes * 8)) || (rc = b->li.alloc((size_t)in->n * 4))) return rc;
+    if (in->n) {
+        HIP_TRY(hipMemcpy(b->planes.p, in->planes, (size_t)in->n * in->n_planes * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->li.p, in->lambda_idx, (size_t)in->n * 4, hipMemcpyHostToDevice));
+    }
+    *out = b.release();
+    return BMO_OK;
+}
+
+int bmo_batch_free(bmo_device_batch* b) {
+    if (b) (void)hipSetDevice(b->device);
+    delete b;
+    return BMO_OK;
+}
+
+int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result** out) {
+    if (!scene || !batch || !opts || !out) return fail(BMO_ERR_INVALID, "null argument");
+    auto R = std::make_unique<bmo_trace_result>();
+    int rc;
+    if (batch->kind == BMO_BEAM_RAY) rc = run_trace<BMO_BEAM_RAY>(scene, batch, opts, R.get());
+    else if (batch->kind == BMO_BEAM_POLARIZED) rc = run_trace<BMO_BEAM_POLARIZED>(scene, batch, opts, R.get());
+    else return fail(BMO_ERR_UNSUPPORTED, "beam kind not built yet");
+    if (rc) return rc;
+    *out = R.release();
+    return BMO_OK;
+}
+
+int bmo_trace(bmo_scene* scene, const bmo_ray_batch* in, const bmo_trace_opts* opts, bmo_trace_result** out) {
+    if (!opts) return fail(BMO_ERR_INVALID, "null opts");
+    bmo_device_batch* b = nullptr;
+    int rc = bmo_batch_upload(scene, in, opts->device, &b);
+    if (rc) return rc;
+    rc = bmo_trace_device(scene, b, opts, out);
+    bmo_batch_free(b);
+    return rc;
+}
+
+int bmo_result_device_hits(bmo_trace_result* r, int32_t det, const double** data, int64_t* count) {
+    if (!r || det < 0 || det >= r->n_detectors) return fail(BMO_ERR_INVALID, "bad detector");
+    *count = r->det_count[det];
+    *data = r->det_data.p ? static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det] : nullptr;
+    return BMO_OK;
+}
+
+int bmo_result_timing(bmo_trace_result* r, double* k, double* t, int32_t* n) {
+    if (!r) return fail(BMO_ERR_INVALID, "null result");
+    if (k) *k = r->kernel_ms;
+    if (t) *t = r->total_ms;
+    if (n) *n = r->n_steps;
+    return BMO_OK;
+}
+
+int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
+    if (!r || !v) return fail(BMO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->device));
+    if (!r->viewed) {
+        const int64_t nn = r->n_nodes, nr = r->n_records;
+        std::vector<int32_t> root, parent, nseg, status, order;
+        std::vector<double> lambda;
+        int rc;
+        if ((rc = dl(root, r->n_root.p, nn)) || (rc = dl(parent, r->n_parent.p, nn)) || (rc = dl(nseg, r->n_nseg.p, nn)) ||
+            (rc = dl(status, r->n_status.p, nn)) || (rc = dl(order, r->order.p, nn)) || (rc = dl(lambda, r->n_lambda.p, nn)))
+            return rc;
+        std::vector<int32_t> rank(nn);
+        for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int32_t)i;
+        r->h_root.resize(nn);
+        r->h_parent.resize(nn);
+        r->h_first_child.assign(nn, -1);
+        r->h_first_rec.resize(nn);
+        r->h_nseg.resize(nn);
+        r->h_status.resize(nn);
+        r->h_aux.assign(nn * 4, 0.0);
+        int64_t acc = 0;
+        for (int64_t i = 0; i < nn; ++i) {
+            const int32_t nd = order[i];
+            r->h_root[i] = root[nd];
+            r->h_parent[i] = parent[nd] < 0 ? -1 : rank[parent[nd]];
+            r->h_nseg[i] = nseg[nd];
+            r->h_status[i] = status[nd];
+            r->h_first_rec[i] = (int32_t)acc;
+            r->h_aux[4 * i] = lambda[nd];
+            acc += nseg[nd];
+        }
+        for (int64_t i = 0; i < nn; ++i) {
+            const int32_t p = r->h_parent[i];
+            if (p >= 0 && (r->h_first_child[p] < 0 || i < r->h_first_child[p])) r->h_first_child[p] = (int32_t)i;
+        }
+        if (acc != nr) return fail(BMO_ERR_INTERNAL, "segment count mismatch");
+        const int P = r->abi_planes;
+        r->h_rec.assign((size_t)P * nr, 0.0);
+        r->h_rec_obj.assign(nr, -1);
+        r->h_rec_shape.assign(nr, -1);
+        std::vector<double> cd;
+        std::vector<int32_t> ci;
+        for (const Chunk& c : r->chunks) {
+            if (c.count == 0) continue;
+            if ((rc = dl(cd, c.d, (size_t)r->nd * c.cap)) || (rc = dl(ci, c.i, (size_t)NI * c.cap))) return rc;
+            for (int64_t j = 0; j < c.count; ++j) {
+                const int32_t nd = ci[I_NODE * c.cap + j], k = ci[I_K * c.cap + j];
+                const int64_t dst = (int64_t)r->h_first_rec[rank[nd]] + k;
+                for (int p = 0; p < P; ++p) r->h_rec[(size_t)p * nr + dst] = cd[(size_t)p * c.cap + j];
+                r->h_rec_obj[dst] = ci[I_OBJ * c.cap + j];
+                r->h_rec_shape[dst] = ci[I_SHAPE * c.cap + j];
+            }
+        }
+        int64_t tot = 0;
+        for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
+        if ((rc = dl(r->h_det, r->det_data.p, (size_t)tot * 9)) || (rc = dl(r->h_det_node, r->det_node.p, (size_t)tot))) return rc;
+        r->viewed = true;
+    }
+    std::memset(v, 0, sizeof *v);
+    v->n_roots = r->n_roots;
+    v->n_nodes = r->n_nodes;
+    v->n_records = r->n_records;
+    v->n_intersect_calls = (int64_t)r->calls;
+    v->n_steps = r->n_steps;
+    v->beam_kind = r->kind;
+    v->rec_planes = r->abi_planes;
+    v->n_detectors = r->n_detectors;
+    v->node_root = r->h_root.data();
+    v->node_parent = r->h_parent.data();
+    v->node_first_child = r->h_first_child.data();
+    v->node_first_rec = r->h_first_rec.data();
+    v->node_nseg = r->h_nseg.data();
+    v->node_status = r->h_status.data();
+    v->node_aux = r->h_aux.data();
+    v->rec_obj = r->h_rec_obj.data();
+    v->rec_shape = r->h_rec_shape.data();
+    v->rec = r->h_rec.data();
+    v->det_count = r->det_count.data();
+    v->det_offset = r->det_offset.data();
+    v->det_node = r->h_det_node.data();
+    v->det_data = r->h_det.data();
+    return BMO_OK;
+}
+
+int bmo_result_free(bmo_trace_result* r) {
+    if (r) (void)hipSetDevice(r->device);
+    delete r;
+    return BMO_OK;
+}
+
+}  // extern "C"

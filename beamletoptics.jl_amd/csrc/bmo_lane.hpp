@@ -1,0 +1,904 @@
+// bmo_lane.hpp — per-lane arithmetic of the trace kernel (gfx950 HIP engine).
+//
+// One lane = one beam node advancing by ONE bounce: tracing_step! (System.jl:57-110) against
+// the scene staged in LDS, followed by interact3d.  Everything here is FP64, written so that
+// the operation order equals the reference's expressions (compiled with -ffp-contract=off);
+// the dual-number type mirrors ForwardDiff's rules so normals are reproduced including the
+// NaN -> central-difference fallback (AbstractSDF.jl:90-95).
+//
+// Code-shape rules (they matter on CDNA: no device calls, small I-cache footprint):
+//   * every routine is force-inlined and every heavy routine has exactly ONE call site:
+//     the SDF leaf switch is instantiated three times in the whole kernel (value evaluation,
+//     central-difference stencil, dual-number gradient); sphere tracing (classification, inside
+//     march and outside march of AbstractSDF.jl:102-181) is one state-machine loop around one SDF
+//     evaluation; trace_one/trace_all (System.jl:57-85) is one loop around one shape intersection;
+//     interact3d decodes the object kind into an action and then runs one copy of each action.
+//
+// What is NOT in the reference and only here:
+//   * the "miss cull": a ray whose line misses a shape's (inflated) bounding sphere, or which is
+//     outside that sphere and receding, can never satisfy the reference's hit test
+//     (dist < eps_ray, AbstractSDF.jl:118) because every SDF here is >= the distance to the
+//     bounding sphere; the reference would burn its 1000 iterations and return `nothing`.
+//     The cull returns that `nothing` at once.  Hits replay the reference's iteration sequence
+//     exactly.  See DESIGN.md "miss cull" for the argument and tests/test_cull.py for the check.
+//
+// The file also compiles with a host compiler (BMO_HD empty) for the sanitizer / lane-emulator
+// build used by tests (tests/emu); that build is test-only and never shipped or dispatched to.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/bmo.h"
+
+#if defined(__HIPCC__)
+#define BMO_HD __host__ __device__ __forceinline__
+#define BMO_NOUNROLL _Pragma("unroll 1")
+#else
+#define BMO_HD inline __attribute__((always_inline))
+#define BMO_NOUNROLL
+#endif
+
+namespace bmo {
+
+#define BMO_NODE_ERR_ORTHO 256
+
+struct SceneView {
+    const bmo_object* objects;
+    const bmo_shape* shapes;
+    const int32_t* children;
+    const double* tris;
+    const double* n_table;
+    int32_t n_objects, n_lambda;
+    double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
+    int32_t march_iters;
+};
+
+struct d3 {
+    double x, y, z;
+};
+struct Hit {
+    double t;
+    d3 n;
+    int32_t obj, shape;  // shape < 0: no intersection
+};
+
+BMO_HD double kinf() { return __builtin_huge_val(); }
+BMO_HD bool sgn(double x) { return __builtin_signbit(x); }
+BMO_HD bool isnan_(double x) { return x != x; }
+BMO_HD Hit no_hit() {
+    Hit h;
+    h.t = kinf();
+    h.n = {0, 0, 0};
+    h.obj = -1;
+    h.shape = -1;
+    return h;
+}
+
+// ------------------------------------------------------------------ scalar rules (Julia Base)
+BMO_HD double jmax(double x, double y) {
+    if (isnan_(x) || isnan_(y)) return x + y;
+    return ((y > x) || (sgn(y) < sgn(x))) ? y : x;
+}
+BMO_HD double jmin(double x, double y) {
+    if (isnan_(x) || isnan_(y)) return x + y;
+    return ((y < x) || (sgn(y) > sgn(x))) ? y : x;
+}
+BMO_HD double jabs(double x) { return fabs(x); }
+BMO_HD double jsqrt(double x) { return sqrt(x); }
+BMO_HD double val(double x) { return x; }
+
+// ------------------------------------------------------------------ ForwardDiff.Dual, 3 partials
+struct Dual {
+    double v, a, b, c;
+};
+BMO_HD double val(const Dual& x) { return x.v; }
+BMO_HD Dual operator+(const Dual& x, const Dual& y) { return {x.v + y.v, x.a + y.a, x.b + y.b, x.c + y.c}; }
+BMO_HD Dual operator-(const Dual& x, const Dual& y) { return {x.v - y.v, x.a - y.a, x.b - y.b, x.c - y.c}; }
+BMO_HD Dual operator+(const Dual& x, double r) { return {x.v + r, x.a, x.b, x.c}; }
+BMO_HD Dual operator+(double r, const Dual& x) { return {r + x.v, x.a, x.b, x.c}; }
+BMO_HD Dual operator-(const Dual& x, double r) { return {x.v - r, x.a, x.b, x.c}; }
+BMO_HD Dual operator-(double r, const Dual& x) { return {r - x.v, -x.a, -x.b, -x.c}; }
+BMO_HD Dual operator-(const Dual& x) { return {-x.v, -x.a, -x.b, -x.c}; }
+BMO_HD Dual operator*(const Dual& x, const Dual& y) {
+    return {x.v * y.v, (x.a * y.v) + (y.a * x.v), (x.b * y.v) + (y.b * x.v), (x.c * y.v) + (y.c * x.v)};
+}
+BMO_HD Dual operator*(const Dual& x, double r) { return {x.v * r, x.a * r, x.b * r, x.c * r}; }
+BMO_HD Dual operator*(double r, const Dual& x) { return {r * x.v, x.a * r, x.b * r, x.c * r}; }
+BMO_HD Dual operator/(const Dual& x, double r) { return {x.v / r, x.a / r, x.b / r, x.c / r}; }
+BMO_HD Dual jsqrt(const Dual& x) {
+    double s = sqrt(x.v);
+    double d = 1.0 / (2.0 * s);
+    return {s, x.a * d, x.b * d, x.c * d};
+}
+BMO_HD Dual jabs(const Dual& x) { return sgn(x.v) ? -x : x; }
+BMO_HD Dual jmax(const Dual& x, const Dual& y) {
+    bool yw = (y.v > x.v) || (sgn(y.v) < sgn(x.v));
+    double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    return {jmax(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
+}
+BMO_HD Dual jmin(const Dual& x, const Dual& y) {
+    bool yw = (y.v < x.v) || (sgn(y.v) > sgn(x.v));
+    double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    return {jmin(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
+}
+BMO_HD Dual jmax(const Dual& x, double y) {
+    double dx = ((y > x.v) || (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
+    return {jmax(x.v, y), x.a * dx, x.b * dx, x.c * dx};
+}
+BMO_HD Dual jmin(const Dual& x, double y) {
+    double dx = ((y < x.v) || (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
+    return {jmin(x.v, y), x.a * dx, x.b * dx, x.c * dx};
+}
+
+template <class T>
+struct v3 {
+    T x, y, z;
+};
+
+BMO_HD double dot3(const d3& a, const d3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+BMO_HD double norm3(const d3& a) { return sqrt(dot3(a, a)); }
+BMO_HD d3 sub3(const d3& a, const d3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+BMO_HD d3 neg3(const d3& a) { return {-a.x, -a.y, -a.z}; }
+BMO_HD d3 cross3(const d3& a, const d3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+BMO_HD d3 axpy3(const d3& p, double s, const d3& d) { return {p.x + s * d.x, p.y + s * d.y, p.z + s * d.z}; }
+BMO_HD d3 normalize_div(const d3& a) {  // normalize(::Point3) = a ./ norm(a)
+    double n = norm3(a);
+    return {a.x / n, a.y / n, a.z / n};
+}
+BMO_HD d3 normalize_inv(const d3& a) {  // normalize(::Vector) = a * inv(norm(a))
+    double inv = 1.0 / norm3(a);
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+template <class T>
+BMO_HD T norm2(const T& x, const T& y) {
+    return jsqrt(x * x + y * y);
+}
+template <class T>
+BMO_HD T norm3t(const T& x, const T& y, const T& z) {
+    return jsqrt((x * x + y * y) + z * z);
+}
+
+// isapprox for reals (Base): default rtol = sqrt(eps) iff atol == 0
+BMO_HD bool isapprox(double x, double y, double atol) {
+    double rtol = atol > 0.0 ? 0.0 : 1.4901161193847656e-08;
+    if (x == y) return true;
+    if (isnan_(x) || isnan_(y) || fabs(x) == kinf() || fabs(y) == kinf()) return false;
+    return fabs(x - y) <= fmax(atol, rtol * fmax(fabs(x), fabs(y)));
+}
+
+// ------------------------------------------------------------------ SDF evaluation
+// _world_to_sdf (AbstractSDF.jl:35-40): rows of the stored transposed orientation, left fold
+template <class T>
+BMO_HD v3<T> to_local(const bmo_shape& s, const v3<T>& pt) {
+    T dx = pt.x - s.pos[0], dy = pt.y - s.pos[1], dz = pt.z - s.pos[2];
+    const double* m = s.tdir;
+    return {(m[0] * dx + m[1] * dy) + m[2] * dz, (m[3] * dx + m[4] * dy) + m[5] * dz, (m[6] * dx + m[7] * dy) + m[8] * dz};
+}
+
+// min(maximum(d), 0) + norm(max.(d, 0))   [== norm(max.(d,0)) + min(max(d1,d2),0): IEEE + commutes]
+template <class T>
+BMO_HD T slab2(const T& dx, const T& dy) {
+    T mx = jmax(dx, dy);
+    T ax = jmax(dx, 0.0), ay = jmax(dy, 0.0);
+    return jmin(mx, 0.0) + norm2(ax, ay);
+}
+
+// leaf SDFs; `pt` is in the parent's frame (world, or the meniscus frame)
+template <class T>
+BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt) {
+    v3<T> p = to_local(s, pt);
+    const int kind = s.kind;
+    if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
+        T r = norm3t(p.x, p.y, p.z);
+        return kind == BMO_SHAPE_SPHERE ? r - s.p[0] : r;
+    }
+    if (kind == BMO_SHAPE_PLANO || kind == BMO_SHAPE_CYLINDER || kind == BMO_SHAPE_RING) {
+        // SphericalLensSDF.jl:60-65, PrimitiveSDF.jl:71-76, :151-166
+        double ra, ha, off, sub;
+        if (kind == BMO_SHAPE_PLANO) {
+            ra = s.p[1] / 2;
+            ha = s.p[0] / 2;
+            off = s.p[0] / 2;
+            sub = 0.0;
+        } else if (kind == BMO_SHAPE_CYLINDER) {
+            ra = s.p[0];
+            ha = s.p[1];
+            off = 0.0;
+            sub = 0.0;
+        } else {
+            ra = s.p[1];
+            ha = s.p[2];
+            off = 0.0;
+            sub = s.p[0];
+        }
+        T r = norm2(p.x, p.z);
+        if (kind == BMO_SHAPE_RING) r = r - sub;
+        T h = kind == BMO_SHAPE_PLANO ? p.y - off : p.y;
+        return slab2(jabs(r) - ra, jabs(h) - ha);
+    }
+    if (kind == BMO_SHAPE_CONVEX || kind == BMO_SHAPE_CUTSPHERE) {  // SphericalLensSDF.jl:219-232, PrimitiveSDF.jl:112-124
+        double radius = s.p[0], w, height;
+        T q1 = norm2(p.x, p.z), q2;
+        if (kind == BMO_SHAPE_CONVEX) {
+            w = s.p[1] / 2;
+            height = s.p[3];
+            q2 = -p.y + radius;
+        } else {
+            height = s.p[1];
+            w = s.p[2];
+            q2 = p.y;
+        }
+        double a = val(q1), b = val(q2);
+        double sv = jmax((height - radius) * (a * a) + (w * w) * (height + radius - 2 * b), height * a - w * b);
+        if (sv < 0) return norm2(q1, q2) - radius;
+        if (a < w) return height - q2;
+        return norm2(q1 - w, q2 - height);
+    }
+    if (kind == BMO_SHAPE_CONCAVE) {  // SphericalLensSDF.jl:159-170
+        double radius = s.p[0], dia = s.p[1], sag = s.p[2];
+        T x0 = p.x + 0.0, z0 = p.z + 0.0;
+        T y1 = p.y + sag / 2;
+        T r = norm2(x0, z0);
+        T sdf1 = slab2(jabs(r) - dia / 2, jabs(y1) - sag / 2);
+        T y2 = p.y + radius;
+        T sdf2 = norm3t(x0, y2, z0) - radius;
+        return jmax(sdf1, -sdf2);
+    }
+    if (kind == BMO_SHAPE_BOX || kind == BMO_SHAPE_PRISM) {  // PrimitiveSDF.jl:41-46, :204-210
+        T qx = jabs(p.x) - s.p[0], qy = jabs(p.y) - s.p[1], qz = jabs(p.z) - s.p[2];
+        T box = norm3t(jmax(qx, 0.0), jmax(qy, 0.0), jmax(qz, 0.0)) + jmin(jmax(qx, jmax(qy, qz)), 0.0);
+        if (kind == BMO_SHAPE_BOX) return box;
+        T pln = (p.x + p.y) / 1.4142135623730951;  // sqrt(2)
+        return jmax(box, pln);
+    }
+    return T{} + kinf();
+}
+
+// leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
+template <class T>
+BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
+    const bool men = s.kind == BMO_SHAPE_MENISCUS;
+    v3<T> p = pt;
+    if (men) p = to_local(s, pt);
+    const int nleaf = men ? 3 : 1;
+    T a = T{}, b = T{}, c = T{};
+    BMO_NOUNROLL
+    for (int q = 0; q < nleaf; ++q) {
+        const bmo_shape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
+        T v = sdf_leaf<T>(leaf, p);
+        if (q == 0) a = v;
+        else if (q == 1) b = v;
+        else c = v;
+    }
+    if (men) return jmax(jmin(a, b), -c);
+    return a;
+}
+
+// sdf(shape, p) for any SDF shape incl. UnionSDF (UnionSDF.jl:53-56, left-fold min) together with
+// the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
+BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t& best_child) {
+    const v3<double> pt{p.x, p.y, p.z};
+    const bool uni = s.kind == BMO_SHAPE_UNION;
+    const int nch = uni ? s.child_count : 1;
+    double best = 0.0;
+    best_child = 0;
+    BMO_NOUNROLL
+    for (int c = 0; c < nch; ++c) {
+        const bmo_shape& ch = uni ? S.shapes[S.children[s.child_begin + c]] : s;
+        double v = sdf_simple<double>(S, ch, pt);
+        if (c == 0) {
+            best = v;
+        } else {
+            if ((v < best) || (v == best && sgn(v) && !sgn(best))) best_child = c;
+            best = jmin(best, v);
+        }
+    }
+    return best;
+}
+
+// normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
+// normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88)
+BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t best_child) {
+    const bmo_shape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
+    v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
+    Dual y = sdf_simple<Dual>(S, sh, x);
+    d3 n = normalize_inv(d3{y.a, y.b, y.c});
+    if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
+    const double e = S.grad_h;
+    double g0 = 0, g1 = 0, g2 = 0;
+    BMO_NOUNROLL
+    for (int q = 0; q < 6; ++q) {  // +x -x +y -y +z -z ; the untouched components get +0.0 / -0.0 like Point3(eps,0,0)
+        const int ax = q >> 1;
+        const bool minus = q & 1;
+        double ox = ax == 0 ? e : 0.0, oy = ax == 1 ? e : 0.0, oz = ax == 2 ? e : 0.0;
+        v3<double> pt = minus ? v3<double>{p.x - ox, p.y - oy, p.z - oz} : v3<double>{p.x + ox, p.y + oy, p.z + oz};
+        double v = sdf_simple<double>(S, sh, pt);
+        double contrib = minus ? -v : v;
+        // f(p+h) - f(p-h): the '+' value is stored first, the '-' value subtracted from it
+        if (ax == 0) g0 = minus ? g0 - v : v;
+        else if (ax == 1) g1 = minus ? g1 - v : v;
+        else g2 = minus ? g2 - v : v;
+        (void)contrib;
+    }
+    return normalize_div(d3{g0, g1, g2});
+}
+
+// ------------------------------------------------------------------ miss cull (see file header)
+// true  => the reference returns `nothing` for this shape and ray (proved, not guessed)
+BMO_HD bool cull_line(const bmo_shape& s, const d3& pos, const d3& dir) {
+    double R = s.bs_radius;
+    if (!(R >= 0.0)) return false;
+    d3 oc{s.bs_center[0] - pos.x, s.bs_center[1] - pos.y, s.bs_center[2] - pos.z};
+    double dd = dot3(dir, dir), b = dot3(oc, dir), cc = dot3(oc, oc), R2 = R * R;
+    if (cc > R2 && b < 0.0) return true;      // outside the sphere and receding
+    if (cc - (b * b) / dd > R2) return true;  // the whole line misses the sphere
+    return false;
+}
+BMO_HD bool cull_receding(const bmo_shape& s, const d3& pos, const d3& dir) {
+    double R = s.bs_radius;
+    if (!(R >= 0.0)) return false;
+    d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
+    return dot3(co, co) > R * R && dot3(co, dir) > 0.0;
+}
+
+// MoellerTrumboreAlgorithm Mesh.jl:203-237
+BMO_HD double moeller_trumbore(const double* f, const d3& pos, const d3& dir, double keps, double leps) {
+    d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
+    d3 E1 = sub3(V2, V1), E2 = sub3(V3, V1);
+    d3 Pv = cross3(dir, E2);
+    double Det = dot3(E1, Pv);
+    if (fabs(Det) < keps) return kinf();
+    d3 Tv = sub3(pos, V1);
+    double invDet = 1 / Det;
+    double u = dot3(Tv, Pv) * invDet;
+    if ((u < 0 - keps) || (u > 1 + keps)) return kinf();
+    d3 Qv = cross3(Tv, E1);
+    double v = dot3(dir, Qv) * invDet;
+    if ((v < 0 - keps) || (u + v > 1 + keps)) return kinf();
+    double t = dot3(E2, Qv) * invDet;
+    if (t < leps) return kinf();
+    return t;
+}
+
+// intersect3d(shape, ray).
+//   Mesh: Mesh.jl:244-267.
+//   SDF:  AbstractSDF.jl:166-181 with _raymarch_outside (:102-125) and _raymarch_inside (:132-159)
+//         run as ONE state machine around one SDF evaluation per iteration:
+//           CLASSIFY: d = sdf(p0); d > eps_srf -> OUT(dir) ; else normal test -> IN or `nothing`
+//           IN:  p += eps_ins*dir, t_in += eps_ins; sdf(p) > 0 -> OUT(-dir) from here (dist = that sdf)
+//           OUT: p += dist*dir', dist = sdf(p), t0 += dist, hit when dist < eps_ray
+//         The reference's _raymarch_outside re-evaluates sdf at its start point; that value equals the
+//         one just computed at the same point, so it is reused (bit-identical, one evaluation less).
+BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0) {
+    const bmo_shape& s = S.shapes[sid];
+    Hit h = no_hit();
+    if (cull_line(s, pos0, dir0)) return h;
+    if (s.kind == BMO_SHAPE_MESH) {
+        int fid = -1;
+        double t0 = kinf();
+        BMO_NOUNROLL
+        for (int i = 0; i < s.tri_count; ++i) {
+            double t = moeller_trumbore(S.tris + 9 * (s.tri_begin + i), pos0, dir0, S.mt_keps, S.mt_leps);
+            if (t < t0) {
+                t0 = t;
+                fid = i;
+            }
+        }
+        if (fid < 0) return h;
+        const double* f = S.tris + 9 * (s.tri_begin + fid);
+        d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
+        d3 n = normalize_div(cross3(sub3(V2, V1), sub3(V3, V1)));  // normal3d(mesh, fID) Mesh.jl:183-192
+        h.t = t0;
+        h.n = normalize_div(n);  // second normalize, Mesh.jl:265
+        h.shape = sid;
+        return h;
+    }
+    enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2 };
+    int phase = CLASSIFY;
+    d3 pos = pos0, dir = dir0;
+    double dist = 0.0, t0 = 0.0, t_in = 0.0;
+    int i_out = 1, i_in = 1;
+    bool back = false;
+    for (;;) {
+        if (phase == INSIDE) {
+            pos = axpy3(pos, S.eps_ins, dir);
+            t_in += S.eps_ins;
+        } else if (phase == OUTSIDE) {
+            pos = axpy3(pos, dist, dir);
+        }
+        int32_t bc;
+        const double d = sdf_any(S, s, pos, bc);
+        bool want_normal = false;
+        if (phase == CLASSIFY) {
+            if (d > S.eps_srf) {
+                phase = OUTSIDE;
+                dist = d;
+                t0 = d;
+                i_out = 1;
+                if (!(i_out <= S.march_iters)) return h;
+                continue;
+            }
+            want_normal = true;
+        } else if (phase == INSIDE) {
+            if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
+                phase = OUTSIDE;
+                back = true;
+                dir = neg3(dir);
+                dist = d;
+                t0 = d;
+                i_out = 1;
+                if (!(i_out <= S.march_iters)) return h;
+                continue;
+            }
+            i_in += 1;
+            if (!(i_in <= S.march_iters)) return h;
+            continue;
+        } else {
+            dist = d;
+            t0 += d;
+            i_out += 1;
+            if (d < S.eps_ray) want_normal = true;
+            else {
+                if (cull_receding(s, pos, dir)) return h;  // provable miss: skip the rest of the 1000 evaluations
+                if (!(i_out <= S.march_iters)) return h;
+                continue;
+            }
+        }
+        // single normal evaluation site (classification on the surface, or hit)
+        (void)want_normal;
+        const d3 n = normal_any(S, s, pos, bc);
+        if (phase == CLASSIFY) {
+            if (dot3(dir, n) <= 0) {
+                phase = INSIDE;
+                t_in = 0.0;
+                i_in = 1;
+                if (!(i_in <= S.march_iters)) return h;
+                continue;
+            }
+            return h;  // on the surface and leaving: no intersection
+        }
+        h.t = back ? t_in - t0 : t0;
+        h.n = n;
+        h.shape = sid;
+        return h;
+    }
+}
+
+// tracing_step! (System.jl:100-110) = trace_one (:74-85) falling back to trace_all (:57-72), written as
+// one loop over "slots": slot -1 is the hinted SHAPE (if any), slots 0..M-1 are the leaf objects.
+// Object-level rules: SingleShape/MultiShape AbstractRay.jl:118-155, plate splitter
+// PlateBeamsplitter.jl:160-187, NonInteractable.jl:19.  `calls` counts the reference's intersect3d calls.
+BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls) {
+    Hit X = no_hit();
+    const int first = hint_shape >= 0 ? -1 : 0;
+    if (hint_shape >= 0) calls += 1;
+    BMO_NOUNROLL
+    for (int o = first; o < S.n_objects; ++o) {
+        int kind = BMO_OBJ_INTERSECTABLE, np = 1;
+        int32_t sh0 = hint_shape, sh1 = -1, sh2 = -1;
+        if (o >= 0) {
+            const bmo_object& ob = S.objects[o];
+            kind = ob.kind;
+            sh0 = ob.shape[0];
+            sh1 = ob.shape[1];
+            sh2 = ob.shape[2];
+            np = (kind == BMO_OBJ_DOUBLET) ? 2 : (kind == BMO_OBJ_CUBE_BS ? 3 : (kind == BMO_OBJ_PLATE_BS ? 2 : 1));
+            if (kind == BMO_OBJ_NONINTERACTABLE) np = 0;
+            if (kind == BMO_OBJ_PLATE_BS) {  // coating first, then substrate
+                int32_t t = sh0;
+                sh0 = sh1;
+                sh1 = t;
+            }
+        }
+        Hit res = no_hit();
+        BMO_NOUNROLL
+        for (int k = 0; k < np; ++k) {
+            const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
+            Hit tmp = intersect_shape(S, sid, pos, dir);
+            if (tmp.shape < 0) continue;
+            if (res.shape < 0) {
+                res = tmp;
+                continue;
+            }
+            if (kind == BMO_OBJ_PLATE_BS) {
+                // res = coating, tmp = substrate: coating wins ties (isapprox) and when strictly nearer
+                if (!(isapprox(res.t, tmp.t, 0.0) || res.t < tmp.t)) res = tmp;
+            } else if (tmp.t < res.t) {
+                res = tmp;
+            }
+        }
+        if (o < 0) {  // hinted shape
+            if (res.shape >= 0) {
+                res.obj = hint_obj;
+                return res;
+            }
+            calls += (uint32_t)S.n_objects;  // fall back to trace_all
+            continue;
+        }
+        if (first == 0 && o == 0) calls += (uint32_t)S.n_objects;
+        if (res.shape < 0) continue;
+        res.obj = o;
+        if (X.shape < 0 || res.t < X.t) X = res;
+    }
+    return X;
+}
+
+// ------------------------------------------------------------------ interactions
+BMO_HD d3 reflection3d(const d3& dir, const d3& n) {  // OpticUtils.jl:7-9
+    double k = 2 * dot3(dir, n);
+    return {dir.x - k * n.x, dir.y - k * n.y, dir.z - k * n.z};
+}
+// refraction3d OpticUtils.jl:31-45; false = unit-length ArgumentError
+BMO_HD bool refraction3d(const d3& dir, const d3& normal, double n1, double n2, d3& out, bool& tir) {
+    if (!isapprox(norm3(dir), 1.0, 0.0)) return false;
+    if (!isapprox(norm3(normal), 1.0, 0.0)) return false;
+    double n = n1 / n2;
+    double ci = -dot3(normal, dir);
+    double st2 = (n * n) * (1 - ci * ci);
+    if (st2 > 1.0) {
+        out = reflection3d(dir, normal);
+        tir = true;
+        return true;
+    }
+    double ct = sqrt(1 - st2);
+    double k = n * ci - ct;
+    out = {n * dir.x + k * normal.x, n * dir.y + k * normal.y, n * dir.z + k * normal.z};
+    tir = false;
+    return true;
+}
+
+// complex helpers (textbook formulas; same convention as the oracle)
+struct cx {
+    double re, im;
+};
+BMO_HD cx cadd(cx a, cx b) { return {a.re + b.re, a.im + b.im}; }
+BMO_HD cx csub(cx a, cx b) { return {a.re - b.re, a.im - b.im}; }
+BMO_HD cx cneg(cx a) { return {-a.re, -a.im}; }
+BMO_HD cx cmul(cx a, cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+BMO_HD cx rmul(double s, cx a) { return {s * a.re, s * a.im}; }
+BMO_HD cx cmulr(cx a, double s) { return {a.re * s, a.im * s}; }
+BMO_HD cx cdiv(cx a, cx b) {
+    double den = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+}
+BMO_HD double cabs2(cx a) { return a.re * a.re + a.im * a.im; }
+
+// one ray of a beam node as the kernel carries it between bounces
+struct RayS {
+    d3 pos, dir;
+    double n;
+    cx E0[3];
+};
+
+enum StepOutcome { OUT_MISS = 0, OUT_STOP = 1, OUT_CONTINUE = 2, OUT_SPLIT = 3 };
+
+struct StepOut {
+    int outcome;
+    int status;              // node status bits to OR in
+    int32_t hint_obj, hint_shape;
+    RayS next;               // OUT_CONTINUE: new segment; OUT_SPLIT: transmitted child
+    RayS refl;               // OUT_SPLIT: reflected child
+    int det_slot;            // >= 0: a detector hit was produced
+    double det[9];
+};
+
+BMO_HD double n_medium(const SceneView& S, int medium, int li) { return S.n_table[medium * S.n_lambda + li]; }
+
+BMO_HD bool isparallel3d(const d3& a, const d3& b) { return isapprox(fabs(dot3(normalize_div(a), normalize_div(b))), 1.0, 2.220446049250313e-16); }
+
+BMO_HD d3 perpendicular_to(const d3& in) {  // deterministic stand-in for the reference's random normal3d(input)
+    double nn = norm3(in);
+    d3 nw = fabs(in.x) > 0.9 * nn ? d3{0, 1, 0} : d3{1, 0, 0};
+    double k = dot3(nw, in), n2 = nn * nn;
+    nw = {nw.x - k * in.x / n2, nw.y - k * in.y / n2, nw.z - k * in.z / n2};
+    return normalize_div(nw);
+}
+
+// res = (A * B) * v for 3x3 complex A, real B given row-major; left folds like StaticArrays
+BMO_HD void mat3_apply(const cx* P, const cx* v, cx* res) {
+    for (int i = 0; i < 3; ++i) res[i] = cadd(cadd(cmul(P[3 * i + 0], v[0]), cmul(P[3 * i + 1], v[1])), cmul(P[3 * i + 2], v[2]));
+}
+
+// _calculate_global_E0 PolarizedRays.jl:165-207 with J = diag(j11, j22, 1)
+BMO_HD void global_E0(const d3& in, const d3& out, const d3& normal, cx j11, cx j22, const cx* E0, cx* res) {
+    bool par = isparallel3d(in, out);
+    d3 v = par ? normal : out;
+    if (isparallel3d(in, normal)) v = perpendicular_to(in);
+    d3 s = normalize_div(cross3(in, v));
+    d3 p1 = cross3(in, s);
+    double Oin[9] = {s.x, s.y, s.z, p1.x, p1.y, p1.z, in.x, in.y, in.z};
+    double Oo[9];
+    d3 mo = neg3(out);
+    bool anti = norm3(sub3(in, mo)) <= 1.4901161193847656e-08 * fmax(norm3(in), norm3(mo));
+    d3 c1 = p1, c2 = in;
+    if (!(par && !anti)) {
+        c1 = cross3(out, s);
+        c2 = out;
+    }
+    Oo[0] = s.x; Oo[1] = c1.x; Oo[2] = c2.x;
+    Oo[3] = s.y; Oo[4] = c1.y; Oo[5] = c2.y;
+    Oo[6] = s.z; Oo[7] = c1.z; Oo[8] = c2.z;
+    cx J[9] = {j11, {0, 0}, {0, 0}, {0, 0}, j22, {0, 0}, {0, 0}, {0, 0}, {1, 0}};
+    cx A[9], P[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A[3 * i + j] = cadd(cadd(rmul(Oo[3 * i + 0], J[0 + j]), rmul(Oo[3 * i + 1], J[3 + j])), rmul(Oo[3 * i + 2], J[6 + j]));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            P[3 * i + j] = cadd(cadd(cmulr(A[3 * i + 0], Oin[0 + j]), cmulr(A[3 * i + 1], Oin[3 + j])), cmulr(A[3 * i + 2], Oin[6 + j]));
+    mat3_apply(P, E0, res);
+}
+BMO_HD bool e0_orthogonal(const d3& dir, const cx* E0) {  // PolarizedRays.jl:54-56
+    cx d = cadd(cadd(rmul(dir.x, E0[0]), rmul(dir.y, E0[1])), rmul(dir.z, E0[2]));
+    return sqrt(cabs2(d)) <= 1e-14;
+}
+BMO_HD void fresnel(double theta, double n, cx& rs, cx& rp, cx& ts, cx& tp) {  // OpticUtils.jl:121-131
+    double ct = cos(theta), st = sin(theta);
+    double x = n * n - st * st;
+    cx r = x >= 0.0 ? cx{sqrt(x), 0.0} : cx{0.0, sqrt(-x)};
+    cx c{ct, 0};
+    rs = cdiv(csub(c, r), cadd(c, r));
+    cx n2c{(n * n) * ct, 0};
+    rp = cdiv(cadd(cx{-(n * n) * ct, 0}, r), cadd(n2c, r));
+    ts = cadd(rs, cx{1, 0});
+    tp = cdiv(cx{2 * n * ct, 0}, cadd(n2c, r));
+}
+BMO_HD double angle3d(const d3& a, const d3& b) {  // LinearAlgebraUtils.jl:103-108
+    double arg = dot3(a, b) / (norm3(a) * norm3(b));
+    arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+    return acos(arg);
+}
+
+BMO_HD d3 hit_point(const RayS& r, double t) { return axpy3(r.pos, t, r.dir); }
+
+// interact3d for one Ray / PolarizedRay: the object kind is decoded into ONE action so that each
+// action body (reflect / refract / split / detectors / polarizer) is inlined exactly once.
+//   reflect   Mirrors.jl:39-69          refract  Lenses.jl:46-126 (+ DoubletLenses.jl:66-76 hint rewrite)
+//   split     ThinBeamsplitter.jl:73-115, PlateBeamsplitter.jl:189-228, CubeBeamsplitter.jl:63-92
+//   detectors Spotdetector.jl:50-61, PSFDetector.jl:77-89     polarizer PolarizationFilter.jl:31-48
+// `opl_before` = optical path length of the beam (incl. parents) up to the START of this segment.
+template <int KIND>
+BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, double lambda, double opl_before, StepOut& o) {
+    const bmo_object& ob = S.objects[X.obj];
+    o.outcome = OUT_STOP;
+    o.hint_obj = o.hint_shape = -1;
+    o.det_slot = -1;
+    enum { A_STOP = 0, A_REFLECT, A_REFRACT, A_SPLIT, A_SPOT, A_PSF, A_POLARIZER };
+    int action = A_STOP;
+    int medium = -1;
+    int32_t hshape = -1;      // Hint(optic) shape of the refracting part
+    int32_t force_hobj = -1;  // composite objects overwrite the hint after the part interaction
+    int32_t force_hshape = -1;
+    int split_mode = 0;       // 0 thin, 1 plate (refract transmitted child), 2 cube (children n := n_glass)
+    switch (ob.kind) {
+        case BMO_OBJ_MIRROR: action = A_REFLECT; break;
+        case BMO_OBJ_REFRACTIVE:
+            action = A_REFRACT;
+            medium = ob.medium[0];
+            hshape = ob.shape[0];
+            break;
+        case BMO_OBJ_DOUBLET: {
+            if (KIND != BMO_BEAM_RAY) break;  // no PolarizedRay method
+            int part = X.shape == ob.shape[0] ? 0 : 1;
+            action = A_REFRACT;
+            medium = ob.medium[part];
+            hshape = ob.shape[part];
+            force_hobj = X.obj;
+            force_hshape = ob.shape[1 - part];
+            break;
+        }
+        case BMO_OBJ_THIN_BS: action = A_SPLIT; break;
+        case BMO_OBJ_PLATE_BS:
+            if (X.shape == ob.shape[0]) {
+                action = A_REFRACT;
+                medium = ob.medium[0];
+                hshape = ob.shape[0];
+                force_hobj = X.obj;
+                force_hshape = ob.shape[1];
+            } else if (X.shape == ob.shape[1]) {
+                action = A_SPLIT;
+                split_mode = 1;
+            }
+            break;
+        case BMO_OBJ_CUBE_BS:
+            if (X.shape == ob.shape[2]) {
+                action = A_SPLIT;
+                split_mode = 2;
+            } else {
+                int part = X.shape == ob.shape[0] ? 0 : 1;
+                action = A_REFRACT;
+                medium = ob.medium[part];
+                hshape = ob.shape[part];
+                force_hobj = X.obj;
+                force_hshape = ob.shape[2];
+            }
+            break;
+        case BMO_OBJ_SPOTDETECTOR: action = A_SPOT; break;
+        case BMO_OBJ_PSFDETECTOR:
+            if (KIND != BMO_BEAM_POLARIZED) action = A_PSF;
+            break;
+        case BMO_OBJ_POLARIZER:
+            if (KIND == BMO_BEAM_POLARIZED) action = A_POLARIZER;
+            break;
+        default: break;  // Intersectable.jl:15
+    }
+
+    const d3 hp = hit_point(ray, X.t);
+    if (action == A_REFLECT || action == A_REFRACT) {
+        d3 nd;
+        double n_out = ray.n;
+        cx j11{-1, 0}, j22{1, 0};
+        int32_t ho = -1, hs = -1;
+        if (action == A_REFLECT) {
+            nd = reflection3d(ray.dir, X.n);
+        } else {
+            d3 normal = X.n;
+            const bool entering = dot3(ray.dir, X.n) < 0;  // isentering AbstractRay.jl:234-237
+            double n1, n2;
+            if (entering) {
+                n1 = ray.n;
+                n2 = n_medium(S, medium, li);
+                ho = X.obj;
+                hs = hshape;
+            } else {
+                n1 = n_medium(S, medium, li);
+                n2 = 1.0;  // refractive_index(system, λ) AbstractSystem.jl:21
+                normal = neg3(normal);
+            }
+            bool tir = false, do_refract = true;
+            if (KIND == BMO_BEAM_POLARIZED) {
+                double th = angle3d(ray.dir, neg3(normal));
+                cx rs, rp, ts, tp;
+                fresnel(th, n2 / n1, rs, rp, ts, tp);
+                if (isapprox(cabs2(rs), 1.0, 1e-6) && isapprox(cabs2(rp), 1.0, 1e-6)) {  // is_internally_reflected
+                    ho = X.obj;
+                    hs = hshape;
+                    n2 = n_medium(S, medium, li);
+                    nd = reflection3d(ray.dir, normal);
+                    j11 = cneg(rs);
+                    j22 = rp;
+                    do_refract = false;
+                } else {
+                    j11 = ts;
+                    j22 = tp;
+                }
+            }
+            if (do_refract) {
+                if (!refraction3d(ray.dir, normal, n1, n2, nd, tir)) {
+                    o.status |= BMO_NODE_ERR_UNIT;
+                    return;
+                }
+                if (KIND != BMO_BEAM_POLARIZED && tir) {
+                    ho = X.obj;
+                    hs = hshape;
+                    n2 = n_medium(S, medium, li);
+                }
+            }
+            n_out = n2;
+        }
+        if (KIND == BMO_BEAM_POLARIZED) {
+            global_E0(ray.dir, nd, X.n, j11, j22, ray.E0, o.next.E0);
+            if (!e0_orthogonal(nd, o.next.E0)) {
+                o.status |= BMO_NODE_ERR_ORTHO;
+                return;
+            }
+        }
+        o.next.pos = hp;
+        o.next.dir = nd;
+        o.next.n = n_out;
+        o.hint_obj = ho;
+        o.hint_shape = hs;
+        if (force_hobj >= 0) {
+            o.hint_obj = force_hobj;
+            o.hint_shape = force_hshape;
+        }
+        o.outcome = OUT_CONTINUE;
+        return;
+    }
+    if (action == A_SPLIT) {
+        // children via the public Ray ctor: dir normalised, n = 1 (ThinBeamsplitter.jl:73-106, Rays.jl:32-42)
+        const d3 rdir = reflection3d(ray.dir, X.n);
+        o.next.pos = o.refl.pos = hp;
+        o.next.n = o.refl.n = 1.0;
+        if (KIND == BMO_BEAM_POLARIZED) {
+            BMO_NOUNROLL
+            for (int w = 0; w < 2; ++w) {
+                const d3 od = w == 0 ? ray.dir : rdir;
+                const cx a = w == 0 ? cx{ob.transmittance, 0} : cx{-ob.reflectance, 0};
+                const cx b = w == 0 ? cx{ob.transmittance, 0} : cx{ob.reflectance, 0};
+                cx e[3];
+                global_E0(ray.dir, od, X.n, a, b, ray.E0, e);
+                for (int c = 0; c < 3; ++c) {
+                    if (w == 0) o.next.E0[c] = e[c];
+                    else o.refl.E0[c] = e[c];
+                }
+            }
+        }
+        o.next.dir = normalize_div(ray.dir);
+        o.refl.dir = normalize_div(rdir);
+        if (KIND == BMO_BEAM_POLARIZED && !(e0_orthogonal(o.next.dir, o.next.E0) && e0_orthogonal(o.refl.dir, o.refl.E0))) {
+            o.status |= BMO_NODE_ERR_ORTHO;
+            return;
+        }
+        if (split_mode == 1) {  // PlateBeamsplitter.jl:203-225
+            const double n_opt = n_medium(S, ob.medium[0], li);
+            const bool ent = dot3(ray.dir, X.n) < 0;
+            const double nt = ent ? n_opt : 1.0, nr = ent ? 1.0 : n_opt;
+            d3 nml = X.n;  // refraction3d(ray, n2) AbstractRay.jl:244-253
+            if (!ent) nml = {nml.x * -1, nml.y * -1, nml.z * -1};
+            d3 nd;
+            bool tir;
+            if (!refraction3d(ray.dir, nml, ray.n, nt, nd, tir)) {
+                o.status |= BMO_NODE_ERR_UNIT;
+                return;
+            }
+            o.next.n = nt;
+            o.refl.n = nr;
+            o.next.dir = normalize_div(nd);  // direction! AbstractRay.jl:83-86
+        } else if (split_mode == 2) {  // CubeBeamsplitter.jl:78-84
+            const double ng = n_medium(S, ob.medium[0], li);
+            o.next.n = ng;
+            o.refl.n = ng;
+        }
+        o.outcome = OUT_SPLIT;
+        return;
+    }
+    if (action == A_SPOT) {
+        const bmo_shape& m = S.shapes[ob.shape[0]];
+        d3 loc{hp.x - m.pos[0], hp.y - m.pos[1], hp.z - m.pos[2]};
+        o.det[0] = dot3(loc, d3{m.dir[0], m.dir[3], m.dir[6]});
+        o.det[1] = dot3(loc, d3{m.dir[2], m.dir[5], m.dir[8]});
+        for (int k = 2; k < 9; ++k) o.det[k] = 0.0;
+        o.det_slot = ob.detector;
+        o.status |= BMO_NODE_DETECTED;
+        return;
+    }
+    if (action == A_PSF) {
+        o.det[0] = hp.x; o.det[1] = hp.y; o.det[2] = hp.z;
+        o.det[3] = ray.dir.x; o.det[4] = ray.dir.y; o.det[5] = ray.dir.z;
+        o.det[6] = opl_before + X.t * ray.n;
+        o.det[7] = fabs(dot3(ray.dir, X.n));
+        o.det[8] = 2 * 3.141592653589793 / lambda;
+        o.det_slot = ob.detector;
+        o.status |= BMO_NODE_DETECTED;
+        return;
+    }
+    if (action == A_POLARIZER) {  // JonesCalculus.jl:29-45: P = Q (R J R') Q, Q = I - d d'
+        const bmo_shape& m = S.shapes[ob.shape[0]];
+        const double* R = m.dir;
+        cx J[9], A[9], P[9], B[9], P2[9];
+        for (int i = 0; i < 9; ++i) J[i] = {ob.jones[2 * i], ob.jones[2 * i + 1]};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                A[3 * i + j] = cadd(cadd(rmul(R[3 * i + 0], J[0 + j]), rmul(R[3 * i + 1], J[3 + j])), rmul(R[3 * i + 2], J[6 + j]));
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                P[3 * i + j] = cadd(cadd(cmulr(A[3 * i + 0], R[3 * j + 0]), cmulr(A[3 * i + 1], R[3 * j + 1])), cmulr(A[3 * i + 2], R[3 * j + 2]));
+        double d[3] = {ray.dir.x, ray.dir.y, ray.dir.z}, Q[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Q[3 * i + j] = (i == j ? 1.0 : 0.0) - d[i] * d[j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                B[3 * i + j] = cadd(cadd(rmul(Q[3 * i + 0], P[0 + j]), rmul(Q[3 * i + 1], P[3 + j])), rmul(Q[3 * i + 2], P[6 + j]));
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                P2[3 * i + j] = cadd(cadd(cmulr(B[3 * i + 0], Q[0 + j]), cmulr(B[3 * i + 1], Q[3 + j])), cmulr(B[3 * i + 2], Q[6 + j]));
+        mat3_apply(P2, ray.E0, o.next.E0);
+        double nrm = sqrt((cabs2(o.next.E0[0]) + cabs2(o.next.E0[1])) + cabs2(o.next.E0[2]));
+        if (isapprox(nrm, ob.cutoff, 0.0)) {
+            o.status |= BMO_NODE_BLOCKED;
+            return;
+        }
+        o.next.pos = hp;
+        o.next.dir = ray.dir;
+        o.next.n = ray.n;
+        if (!e0_orthogonal(o.next.dir, o.next.E0)) {
+            o.status |= BMO_NODE_ERR_ORTHO;
+            return;
+        }
+        o.outcome = OUT_CONTINUE;
+        return;
+    }
+}
+
+}  // namespace bmo

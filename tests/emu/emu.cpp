@@ -1,0 +1,238 @@
+// TEST-ONLY host build of the engine's per-lane code (csrc/bmo_lane.hpp).
+//
+// Purpose: (1) debug/sanitize the lane arithmetic on the CPU (GPU ASan is not available on the
+// pool), (2) check lane code == oracle without spending GPU minutes.  It walks the same
+// bounce-synchronous schedule as step_kernel, one "lane" at a time.  It is NOT a fallback: the
+// product package never loads it (see beamletoptics.jl_amd/abi.py: the engine is libbmo_hip.so only).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../beamletoptics.jl_amd/csrc/bmo_lane.hpp"
+
+using namespace bmo;
+
+namespace {
+struct Rec {
+    RayS ray;
+    Hit X;
+    int node, k, hobj, hshape, flags;
+    double opl;
+};
+struct NodeE {
+    int root, parent, nseg, status, li, hit_det;
+    unsigned long long key;
+    double lambda, hit[9];
+};
+struct ResultE {
+    std::vector<int32_t> root, parent, first_child, first_rec, nseg, status, rec_obj, rec_shape, det_node;
+    std::vector<double> aux, rec, det;
+    std::vector<int64_t> det_count, det_offset;
+};
+
+template <int KIND>
+void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v) {
+    SceneView S;
+    S.objects = d->objects;
+    S.shapes = d->shapes;
+    S.children = d->children;
+    S.tris = d->tris;
+    S.n_table = d->n_table;
+    S.n_objects = d->n_objects;
+    S.n_lambda = d->n_lambda;
+    S.eps_srf = d->eps_srf;
+    S.eps_ray = d->eps_ray;
+    S.eps_ins = d->eps_ins;
+    S.mt_keps = d->mt_keps;
+    S.mt_leps = d->mt_leps;
+    S.grad_h = d->grad_h;
+    S.march_iters = d->march_iters;
+    const int64_t n = in->n;
+    const double* P = in->planes;
+    std::vector<NodeE> nodes(n);
+    std::vector<Rec> cur(n), all;
+    for (int64_t j = 0; j < n; ++j) {
+        Rec& r = cur[j];
+        r.ray.pos = {P[0 * n + j], P[1 * n + j], P[2 * n + j]};
+        r.ray.dir = {P[3 * n + j], P[4 * n + j], P[5 * n + j]};
+        r.ray.n = P[7 * n + j];
+        if (KIND == BMO_BEAM_POLARIZED)
+            for (int c = 0; c < 3; ++c) r.ray.E0[c] = {P[(8 + 2 * c) * n + j], P[(9 + 2 * c) * n + j]};
+        r.node = (int)j;
+        r.k = 0;
+        r.hobj = r.hshape = -1;
+        r.flags = (1 < opts->r_max) ? 0 : 1;
+        r.opl = 0;
+        nodes[j] = NodeE{(int)j, -1, 1, 0, in->lambda_idx[j], -1, ((unsigned long long)j) << 32, P[6 * n + j], {0}};
+    }
+    unsigned long long calls = 0;
+    int steps = 0;
+    while (!cur.empty()) {
+        std::vector<Rec> surv, kids;
+        for (Rec& r : cur) {
+            StepOut o;
+            o.outcome = OUT_MISS;
+            o.status = 0;
+            o.hint_obj = o.hint_shape = -1;
+            o.det_slot = -1;
+            uint32_t c = 0;
+            int status = 0;
+            bool survive = false;
+            Hit X;
+            X.shape = -1;
+            X.obj = -1;
+            X.t = kinf();
+            X.n = {0, 0, 0};
+            NodeE nd = nodes[r.node];
+            double opl_next = 0;
+            if (r.flags & 1) {
+                status = BMO_NODE_RMAX;
+            } else {
+                X = tracing_step(S, r.ray.pos, r.ray.dir, r.hobj, r.hshape, c);
+                if (X.shape < 0) status = BMO_NODE_MISS;
+                else {
+                    interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
+                    status = o.status;
+                    opl_next = r.opl + X.t * r.ray.n;
+                    if (o.outcome == OUT_CONTINUE) survive = true;
+                    else if (o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                    else status |= BMO_NODE_STOPPED;
+                }
+            }
+            calls += c;
+            r.X = X;
+            if (!survive) {
+                nodes[r.node].nseg = r.k + 1;
+                nodes[r.node].status = status;
+                if (o.det_slot >= 0) {
+                    nodes[r.node].hit_det = o.det_slot;
+                    std::memcpy(nodes[r.node].hit, o.det, sizeof o.det);
+                }
+            }
+            if (survive) {
+                Rec q;
+                q.ray = o.next;
+                q.node = r.node;
+                q.k = r.k + 1;
+                q.hobj = o.hint_obj;
+                q.hshape = o.hint_shape;
+                q.flags = (r.k + 2 < opts->r_max) ? 0 : 1;
+                q.opl = opl_next;
+                surv.push_back(q);
+            }
+            if (o.outcome == OUT_SPLIT && !(r.flags & 1) && X.shape >= 0) {
+                unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
+                for (int w = 0; w < 2; ++w) {
+                    NodeE c2{(int)root, r.node, 1, 0, nd.li, -1, (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull)),
+                             nd.lambda, {0}};
+                    nodes.push_back(c2);
+                    Rec q;
+                    q.ray = w == 0 ? o.next : o.refl;
+                    q.node = (int)nodes.size() - 1;
+                    q.k = 0;
+                    q.hobj = q.hshape = -1;
+                    q.flags = (1 < opts->r_max) ? 0 : 1;
+                    q.opl = opl_next;
+                    kids.push_back(q);
+                }
+            }
+        }
+        all.insert(all.end(), cur.begin(), cur.end());
+        cur = surv;
+        cur.insert(cur.end(), kids.begin(), kids.end());
+        steps += 1;
+    }
+    // canonical order
+    const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
+    std::vector<int> order(nn), rank(nn);
+    for (int64_t i = 0; i < nn; ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].key < nodes[b].key; });
+    for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int)i;
+    const int PL = KIND == BMO_BEAM_RAY ? 11 : 17;
+    R.root.resize(nn);
+    R.parent.resize(nn);
+    R.first_child.assign(nn, -1);
+    R.first_rec.resize(nn);
+    R.nseg.resize(nn);
+    R.status.resize(nn);
+    R.aux.assign(nn * 4, 0.0);
+    int64_t acc = 0;
+    for (int64_t i = 0; i < nn; ++i) {
+        const NodeE& nd = nodes[order[i]];
+        R.root[i] = nd.root;
+        R.parent[i] = nd.parent < 0 ? -1 : rank[nd.parent];
+        R.nseg[i] = nd.nseg;
+        R.status[i] = nd.status;
+        R.first_rec[i] = (int32_t)acc;
+        R.aux[4 * i] = nd.lambda;
+        acc += nd.nseg;
+    }
+    for (int64_t i = 0; i < nn; ++i)
+        if (R.parent[i] >= 0 && (R.first_child[R.parent[i]] < 0 || i < R.first_child[R.parent[i]])) R.first_child[R.parent[i]] = (int32_t)i;
+    R.rec.assign((size_t)PL * nr, 0.0);
+    R.rec_obj.assign(nr, -1);
+    R.rec_shape.assign(nr, -1);
+    for (const Rec& r : all) {
+        int64_t dst = (int64_t)R.first_rec[rank[r.node]] + r.k;
+        double vals[17] = {r.ray.pos.x, r.ray.pos.y, r.ray.pos.z, r.ray.dir.x, r.ray.dir.y, r.ray.dir.z, r.ray.n, r.X.t, r.X.n.x, r.X.n.y, r.X.n.z,
+                           r.ray.E0[0].re, r.ray.E0[0].im, r.ray.E0[1].re, r.ray.E0[1].im, r.ray.E0[2].re, r.ray.E0[2].im};
+        for (int p = 0; p < PL; ++p) R.rec[(size_t)p * nr + dst] = vals[p];
+        R.rec_obj[dst] = r.X.obj;
+        R.rec_shape[dst] = r.X.shape;
+    }
+    const int ndet = d->n_detectors;
+    R.det_count.assign(ndet, 0);
+    R.det_offset.assign(ndet, 0);
+    for (int q = 0; q < ndet; ++q) {
+        R.det_offset[q] = (int64_t)R.det_node.size();
+        for (int64_t i = 0; i < nn; ++i) {
+            const NodeE& nd = nodes[order[i]];
+            if (nd.hit_det != q) continue;
+            R.det_node.push_back((int32_t)i);
+            R.det.insert(R.det.end(), nd.hit, nd.hit + 9);
+        }
+        R.det_count[q] = (int64_t)R.det_node.size() - R.det_offset[q];
+    }
+    std::memset(v, 0, sizeof *v);
+    v->n_roots = n;
+    v->n_nodes = nn;
+    v->n_records = nr;
+    v->n_intersect_calls = (int64_t)calls;
+    v->n_steps = steps;
+    v->beam_kind = KIND;
+    v->rec_planes = PL;
+    v->n_detectors = ndet;
+    v->node_root = R.root.data();
+    v->node_parent = R.parent.data();
+    v->node_first_child = R.first_child.data();
+    v->node_first_rec = R.first_rec.data();
+    v->node_nseg = R.nseg.data();
+    v->node_status = R.status.data();
+    v->node_aux = R.aux.data();
+    v->rec_obj = R.rec_obj.data();
+    v->rec_shape = R.rec_shape.data();
+    v->rec = R.rec.data();
+    v->det_count = R.det_count.data();
+    v->det_offset = R.det_offset.data();
+    v->det_node = R.det_node.data();
+    v->det_data = R.det.data();
+}
+}  // namespace
+
+extern "C" {
+int bmo_emu_trace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, void** handle, bmo_trace_result_view* v) {
+    auto* R = new ResultE();
+    if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v);
+    else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v);
+    else {
+        delete R;
+        return BMO_ERR_UNSUPPORTED;
+    }
+    *handle = R;
+    return BMO_OK;
+}
+int bmo_emu_free(void* h) {
+    delete static_cast<ResultE*>(h);
+    return 0;
+}
+}
