@@ -851,6 +851,15 @@ int bmo_result_device_hits(bmo_trace_result* r, int32_t det, const double** data
     return BMO_OK;
 }
 
+int bmo_result_copy_hits(bmo_trace_result* r, int32_t det, double* dst, int64_t max_hits) {
+    if (!r || det < 0 || det >= r->n_detectors || !dst) return fail(BMO_ERR_INVALID, "bad argument");
+    const int64_t n = std::min<int64_t>(max_hits, r->det_count[det]);
+    if (n <= 0) return BMO_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpy(dst, static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det], (size_t)n * 72, hipMemcpyDeviceToDevice));
+    return BMO_OK;
+}
+
 int bmo_result_timing(bmo_trace_result* r, double* k, double* t, int32_t* n) {
     if (!r) return fail(BMO_ERR_INVALID, "null result");
     if (k) *k = r->kernel_ms;

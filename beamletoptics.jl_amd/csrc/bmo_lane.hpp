@@ -40,7 +40,6 @@
 
 namespace bmo {
 
-#define BMO_NODE_ERR_ORTHO 256
 
 struct SceneView {
     const bmo_object* objects;

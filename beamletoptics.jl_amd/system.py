@@ -246,6 +246,17 @@ class Engine:
         abi.check(self.lib, self.lib.bmo_result_device_hits(res, slot, C.byref(p), C.byref(n)), "bmo_result_device_hits")
         return C.cast(p, C.c_void_p).value or 0, n.value
 
+    def result_copy_hits(self, res, slot, dst_device_ptr, max_hits):
+        abi.check(self.lib, self.lib.bmo_result_copy_hits(res, slot, C.c_void_p(dst_device_ptr), max_hits), "bmo_result_copy_hits")
+
+    def result_counts(self, res):
+        """(n_intersect_calls, n_records, n_nodes, n_steps, det_counts) without downloading the segment log."""
+        ms, tot, nl = self.result_timing(res)
+        cnt = []
+        for slot in range(len(self.scene.detectors)):
+            cnt.append(self.result_device_hits(res, slot)[1])
+        return cnt
+
     def free_result(self, res):
         self.lib.bmo_result_free(res)
 
