@@ -113,7 +113,7 @@ class TraceResult:
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENGINE_PATH = os.path.join(_HERE, "csrc", "libbmo_hip.so")
+ENGINE_PATH = os.environ.get("BMO_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libbmo_hip.so")  # env: A/B builds of the HIP engine
 _engine = None
 
 

@@ -18,12 +18,14 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <unistd.h>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -149,8 +151,11 @@ __device__ inline int prefix_rank(unsigned long long mask) {
     return __popcll(mask & ((1ull << lane_id()) - 1ull));
 }
 
+#ifndef BMO_MIN_WAVES
+#define BMO_MIN_WAVES 2  /* <= 256 VGPRs: 2 waves/SIMD measured 1.4x faster than 1; 4 (128 VGPRs) spills */
+#endif
 template <int KIND>
-__global__ __launch_bounds__(256) void step_kernel(StepParams P) {
+__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const char* blob = P.blob;
     if (P.use_lds) {
@@ -363,13 +368,69 @@ __global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, 
 }
 
 // ------------------------------------------------------------------ host-side objects
+// Device memory pool: hipMalloc/hipFree of the multi-GB segment log cost more than the trace itself, so
+// freed blocks are kept per device and reused by the next trace (same sizes every call for a fixed batch).
+struct PoolBlock {
+    void* p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+
+void* pool_take(size_t bytes, int device, size_t& got) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i) {
+        const PoolBlock& b = g_pool[i];
+        if (b.device != device || b.bytes < bytes || b.bytes > bytes + bytes / 4 + 4096) continue;
+        if (best < 0 || b.bytes < g_pool[best].bytes) best = i;
+    }
+    if (best < 0) return nullptr;
+    void* p = g_pool[best].p;
+    got = g_pool[best].bytes;
+    g_pool_bytes -= got;
+    g_pool.erase(g_pool.begin() + best);
+    return p;
+}
+void pool_give(void* p, size_t bytes, int device) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back({p, bytes, device});
+    g_pool_bytes += bytes;
+}
+void pool_release_all() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& b : g_pool) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    (void)hipSetDevice(cur);
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int device = 0;
     int alloc(size_t b) {
         release();
         if (b == 0) b = 16;
+        (void)hipGetDevice(&device);
+        size_t got = 0;
+        if (void* q = pool_take(b, device, got)) {
+            p = q;
+            bytes = got;
+            return BMO_OK;
+        }
         hipError_t e = hipMalloc(&p, b);
+        if (e != hipSuccess) {
+            pool_release_all();  // give cached blocks back and retry once
+            e = hipMalloc(&p, b);
+        }
         if (e != hipSuccess) {
             p = nullptr;
             return fail(BMO_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -378,7 +439,7 @@ struct DevBuf {
         return BMO_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_give(p, bytes, device);
         p = nullptr;
         bytes = 0;
     }
@@ -456,13 +517,37 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     R->nd = L::ND;
     R->abi_planes = L::ABI;
 
-    hipStream_t stream;
-    HIP_TRY(hipStreamCreate(&stream));
-    hipEvent_t ev_a, ev_b, ev_t0, ev_t1;
-    HIP_TRY(hipEventCreate(&ev_a));
-    HIP_TRY(hipEventCreate(&ev_b));
-    HIP_TRY(hipEventCreate(&ev_t0));
-    HIP_TRY(hipEventCreate(&ev_t1));
+    auto wall0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg_on()) return;
+        auto t = std::chrono::steady_clock::now();
+        DBG("phase %-10s %.3f ms", what, std::chrono::duration<double, std::milli>(t - wall0).count());
+        wall0 = t;
+    };
+    // one trace stream + timing events per device, created once (hipStreamCreate costs ~1 ms)
+    struct DevCtx {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    };
+    static std::mutex ctx_mu;
+    static std::vector<std::pair<int, DevCtx>> ctxs;
+    DevCtx ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx_mu);
+        bool found = false;
+        for (auto& c : ctxs)
+            if (c.first == device) {
+                ctx = c.second;
+                found = true;
+            }
+        if (!found) {
+            HIP_TRY(hipStreamCreate(&ctx.stream));
+            for (int q = 0; q < 4; ++q) HIP_TRY(hipEventCreate(&ctx.ev[q]));
+            ctxs.emplace_back(device, ctx);
+        }
+    }
+    hipStream_t stream = ctx.stream;
+    hipEvent_t ev_a = ctx.ev[0], ev_b = ctx.ev[1], ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
     HIP_TRY(hipEventRecord(ev_t0, stream));
 
     // node arrays: roots + room for children (grown on demand)
@@ -558,6 +643,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
                            (const int32_t*)batch->li.p, n, cur, node_arrays(), opts->r_max);
     }
+    lap("setup");
     const uint32_t blob_bytes = (uint32_t)scene->blob.size();
     const int use_lds = (blob_bytes <= 120 * 1024 && !getenv("BMO_NO_LDS")) ? 1 : 0;
     DBG("roots initialised n=%lld blob=%u use_lds=%d", (long long)n, blob_bytes, use_lds);
@@ -608,6 +694,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         h_ctr.next_count = 0;
         HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
     }
+    lap("steps");
     R->n_nodes = n_nodes;
     R->calls = h_ctr.calls;
     R->n_steps = steps;
@@ -633,6 +720,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         std::swap(R->order.p, vals_out.p);
         std::swap(R->order.bytes, vals_out.bytes);
     }
+    lap("order");
     // ---- detector hits in reference push! order: flags -> exclusive scan -> gather
     const int nd = R->n_detectors;
     R->det_count.assign(nd, 0);
@@ -668,16 +756,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
                            (int32_t*)R->det_node.p);
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    lap("hits");
     HIP_TRY(hipEventRecord(ev_t1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     float tms = 0;
     HIP_TRY(hipEventElapsedTime(&tms, ev_t0, ev_t1));
     R->total_ms = tms;
-    (void)hipEventDestroy(ev_a);
-    (void)hipEventDestroy(ev_b);
-    (void)hipEventDestroy(ev_t0);
-    (void)hipEventDestroy(ev_t1);
-    (void)hipStreamDestroy(stream);
     return BMO_OK;
 }
 
@@ -785,6 +869,11 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
 
 int bmo_scene_destroy(bmo_scene* s) {
     delete s;
+    return BMO_OK;
+}
+
+int bmo_pool_release(void) {
+    pool_release_all();
     return BMO_OK;
 }
 

@@ -323,15 +323,19 @@ BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_
 }
 
 // ------------------------------------------------------------------ miss cull (see file header)
-// true  => the reference returns `nothing` for this shape and ray (proved, not guessed)
-BMO_HD bool cull_line(const bmo_shape& s, const d3& pos, const d3& dir) {
+// Returns < 0 when the reference provably returns `nothing` for this shape and ray (the line misses the
+// inflated bounding sphere, or the origin is outside it and receding); otherwise a lower bound (>= 0) of the
+// ray parameter t of any hit: the hit point lies inside the sphere, so t >= the sphere entry parameter.
+BMO_HD double cull_entry(const bmo_shape& s, const d3& pos, const d3& dir) {
     double R = s.bs_radius;
-    if (!(R >= 0.0)) return false;
+    if (!(R >= 0.0)) return 0.0;
     d3 oc{s.bs_center[0] - pos.x, s.bs_center[1] - pos.y, s.bs_center[2] - pos.z};
     double dd = dot3(dir, dir), b = dot3(oc, dir), cc = dot3(oc, oc), R2 = R * R;
-    if (cc > R2 && b < 0.0) return true;      // outside the sphere and receding
-    if (cc - (b * b) / dd > R2) return true;  // the whole line misses the sphere
-    return false;
+    if (!(cc > R2)) return 0.0;          // origin inside the sphere: no bound
+    if (b < 0.0) return -1.0;            // outside and receding
+    double disc = b * b - dd * (cc - R2);
+    if (disc < 0.0) return -1.0;         // the whole line misses the sphere
+    return (b - sqrt(disc)) / dd;
 }
 BMO_HD bool cull_receding(const bmo_shape& s, const d3& pos, const d3& dir) {
     double R = s.bs_radius;
@@ -368,10 +372,18 @@ BMO_HD double moeller_trumbore(const double* f, const d3& pos, const d3& dir, do
 //           OUT: p += dist*dir', dist = sdf(p), t0 += dist, hit when dist < eps_ray
 //         The reference's _raymarch_outside re-evaluates sdf at its start point; that value equals the
 //         one just computed at the same point, so it is reused (bit-identical, one evaluation less).
-BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0) {
+//   `t_limit`: a hit whose t exceeds it cannot win trace_all's strict `<` selection (System.jl:67), so the
+//   outside march stops once its running t0 exceeds it.  t0 only grows by positive steps until the final
+//   sub-tolerance step (>= -1e-8*dist for these 1-Lipschitz SDFs), so with the caller's 1e-6 margin the
+//   pruned shape is provably a loser; results are unchanged (DESIGN.md "nearest-hit prune").
+BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit) {
     const bmo_shape& s = S.shapes[sid];
     Hit h = no_hit();
-    if (cull_line(s, pos0, dir0)) return h;
+    {
+        const double t_lb = cull_entry(s, pos0, dir0);
+        if (t_lb < 0.0) return h;                            // provable `nothing`
+        if (t_lb * (1.0 - 1e-9) - 1e-9 > t_limit) return h;  // provable loser of the nearest-hit selection
+    }
     if (s.kind == BMO_SHAPE_MESH) {
         int fid = -1;
         double t0 = kinf();
@@ -415,6 +427,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
                 t0 = d;
                 i_out = 1;
                 if (!(i_out <= S.march_iters)) return h;
+                if (t0 > t_limit) return h;
                 continue;
             }
             want_normal = true;
@@ -439,6 +452,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
             if (d < S.eps_ray) want_normal = true;
             else {
                 if (cull_receding(s, pos, dir)) return h;  // provable miss: skip the rest of the 1000 evaluations
+                if (!back && t0 > t_limit) return h;        // provable loser of the nearest-hit selection
                 if (!(i_out <= S.march_iters)) return h;
                 continue;
             }
@@ -493,7 +507,8 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
         BMO_NOUNROLL
         for (int k = 0; k < np; ++k) {
             const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
-            Hit tmp = intersect_shape(S, sid, pos, dir);
+            const double lim = (o >= 0 && X.shape >= 0) ? X.t + 1e-6 * (1.0 + X.t) : kinf();
+            Hit tmp = intersect_shape(S, sid, pos, dir, lim);
             if (tmp.shape < 0) continue;
             if (res.shape < 0) {
                 res = tmp;

@@ -236,6 +236,8 @@ int bmo_device_count(void);
 
 int bmo_scene_create(const bmo_scene_desc* desc, bmo_scene** out);
 int bmo_scene_destroy(bmo_scene* scene);
+/* The engine keeps freed device blocks in a per-device pool for reuse by the next trace; this returns them to HIP. */
+int bmo_pool_release(void);
 
 /* One call = solve_system!(system, group; r_max) for a fresh (un-solved) batch:
  * upload, trace on the device, canonicalise, download.                            */
