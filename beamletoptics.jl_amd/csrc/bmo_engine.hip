@@ -105,6 +105,11 @@ template <>
 struct Layout<BMO_BEAM_POLARIZED> {
     static constexpr int ABI = 17, ND = 18, OPL = 17;
 };
+//   GAUSSIAN:  chief 0-10 | waist 11-21 | divergence 22-32 | 33 lenA 34 lenB 35 oplC 36 oplW 37 oplD
+template <>
+struct Layout<BMO_BEAM_GAUSSIAN> {
+    static constexpr int ABI = 33, ND = 38, OPL = 35;
+};
 constexpr int NI = 7;
 enum { I_NODE = 0, I_K = 1, I_HOBJ = 2, I_HSHAPE = 3, I_OBJ = 4, I_SHAPE = 5, I_FLAGS = 6 };
 enum { F_DEAD = 1 };
@@ -132,8 +137,10 @@ struct NodeArrays {
     int32_t* hit_det;
     unsigned long long* key;  // root<<32 | depth<<26 | path
     double* lambda;
-    double* hit;  // [cap][9]
+    double* hit;  // [cap][9 * hit_sub]
+    double* aux;  // [cap][4]: Gaussian l0 (length of parent chief), w0, Re(E0), Im(E0)
     int64_t cap;
+    int32_t hit_sub;  // detector records per node: 1 (Ray / PolarizedRay), 3 (GaussianBeamlet: chief, waist, divergence)
 };
 
 struct StepParams {
@@ -317,6 +324,171 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
     if (lane_id() == 0 && c) atomicAdd(&P.ctr->calls, (unsigned long long)c);
 }
 
+
+// ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
+__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const char* blob = P.blob;
+    if (P.use_lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(P.blob);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
+        __syncthreads();
+        blob = lds;
+    }
+    SceneView S = view_of(blob);
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = P.cur.count, cap = P.cur.cap;
+    const bool valid = j < m;
+    bool survive = false, split = false;
+    int32_t node = -1, k = 0;
+    GaussIn g;
+    GaussOut o;
+    o.outcome = OUT_MISS;
+    uint32_t calls = 0;
+    if (valid) {
+        double* D = P.cur.d;
+        int32_t* I = P.cur.i;
+        node = I[I_NODE * cap + j];
+        k = I[I_K * cap + j];
+        const int32_t flags = I[I_FLAGS * cap + j];
+        auto ld = [&](int base, RayS& r) {
+            r.pos = {D[(base + 0) * cap + j], D[(base + 1) * cap + j], D[(base + 2) * cap + j]};
+            r.dir = {D[(base + 3) * cap + j], D[(base + 4) * cap + j], D[(base + 5) * cap + j]};
+            r.n = D[(base + 6) * cap + j];
+        };
+        ld(0, g.c);
+        ld(11, g.w);
+        ld(22, g.d);
+        g.hint_obj = I[I_HOBJ * cap + j];
+        g.hint_shape = I[I_HSHAPE * cap + j];
+        g.lenA = D[33 * cap + j];
+        g.lenB = D[34 * cap + j];
+        g.oplC = D[35 * cap + j];
+        g.oplW = D[36 * cap + j];
+        g.oplD = D[37 * cap + j];
+        g.li = P.nodes.li[node];
+        g.lambda = P.nodes.lambda[node];
+        g.l0 = P.nodes.aux[(int64_t)node * 4 + 0];
+        g.w0 = P.nodes.aux[(int64_t)node * 4 + 1];
+        g.E0 = {P.nodes.aux[(int64_t)node * 4 + 2], P.nodes.aux[(int64_t)node * 4 + 3]};
+        int status = 0;
+        o.Xc = o.Xw = o.Xd = no_hit();
+        if (flags & F_DEAD) {
+            status = BMO_NODE_RMAX;
+        } else {
+            gauss_step(S, g, o, calls);
+            status = o.status;
+            if (o.outcome == OUT_CONTINUE) survive = true;
+            else if (o.outcome == OUT_SPLIT) {
+                split = true;
+                status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+            } else if (o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
+        }
+        auto st = [&](int base, const Hit& X) {
+            D[(base + 7) * cap + j] = X.t;
+            D[(base + 8) * cap + j] = X.n.x;
+            D[(base + 9) * cap + j] = X.n.y;
+            D[(base + 10) * cap + j] = X.n.z;
+        };
+        st(0, o.Xc);
+        st(11, o.Xw);
+        st(22, o.Xd);
+        I[I_OBJ * cap + j] = o.Xc.obj;
+        I[I_SHAPE * cap + j] = o.Xc.shape;
+        if (!survive) {
+            P.nodes.nseg[node] = k + 1;
+            P.nodes.status[node] = status;
+            if (o.det_slot >= 0 && !(flags & F_DEAD)) {
+                P.nodes.hit_det[node] = o.det_slot;
+                for (int c = 0; c < 27; ++c) P.nodes.hit[(int64_t)node * 27 + c] = o.det[c];
+            }
+        }
+    }
+    const unsigned long long m_surv = __ballot(survive);
+    const unsigned long long m_split = __ballot(split);
+    const int n_surv = __popcll(m_surv), n_split = __popcll(m_split);
+    unsigned long long base = 0, nbase = 0;
+    if (n_surv + n_split > 0) {
+        if (lane_id() == 0) {
+            base = atomicAdd(&P.ctr->next_count, (unsigned long long)(n_surv + 2 * n_split));
+            if (n_split) nbase = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * n_split));
+        }
+        base = __shfl(base, 0);
+        nbase = __shfl(nbase, 0);
+    }
+    const int64_t ncap = P.nxt.cap;
+    auto write_next = [&](int64_t slot, const RayS& c, const RayS& w, const RayS& d, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl,
+                          double lenA, double lenB, double oplC, double oplW, double oplD) {
+        if (slot >= ncap) {
+            atomicAdd(&P.ctr->overflow, 1ull);
+            return;
+        }
+        double* D = P.nxt.d;
+        int32_t* I = P.nxt.i;
+        auto wr = [&](int bs, const RayS& r) {
+            D[(bs + 0) * ncap + slot] = r.pos.x;
+            D[(bs + 1) * ncap + slot] = r.pos.y;
+            D[(bs + 2) * ncap + slot] = r.pos.z;
+            D[(bs + 3) * ncap + slot] = r.dir.x;
+            D[(bs + 4) * ncap + slot] = r.dir.y;
+            D[(bs + 5) * ncap + slot] = r.dir.z;
+            D[(bs + 6) * ncap + slot] = r.n;
+        };
+        wr(0, c);
+        wr(11, w);
+        wr(22, d);
+        D[33 * ncap + slot] = lenA;
+        D[34 * ncap + slot] = lenB;
+        D[35 * ncap + slot] = oplC;
+        D[36 * ncap + slot] = oplW;
+        D[37 * ncap + slot] = oplD;
+        I[I_NODE * ncap + slot] = nd;
+        I[I_K * ncap + slot] = kk;
+        I[I_HOBJ * ncap + slot] = ho;
+        I[I_HSHAPE * ncap + slot] = hs;
+        I[I_FLAGS * ncap + slot] = fl;
+    };
+    if (survive) {
+        const int64_t slot = (int64_t)base + prefix_rank(m_surv);
+        const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+        write_next(slot, o.nc, o.nw, o.nd, node, k + 1, o.hint_obj, o.hint_shape, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+    }
+    if (split) {
+        const int r = prefix_rank(m_split);
+        const int64_t slot = (int64_t)base + n_surv + 2 * r;
+        const int64_t cn = (int64_t)nbase + 2 * r;
+        if (cn + 1 < P.nodes.cap) {
+            const unsigned long long pkey = P.nodes.key[node];
+            const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+            for (int w = 0; w < 2; ++w) {
+                const int64_t c = cn + w;
+                P.nodes.root[c] = (int32_t)root;
+                P.nodes.parent[c] = node;
+                P.nodes.nseg[c] = 1;
+                P.nodes.status[c] = 0;
+                P.nodes.li[c] = g.li;
+                P.nodes.lambda[c] = g.lambda;
+                P.nodes.hit_det[c] = -1;
+                P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                P.nodes.aux[c * 4 + 0] = o.child_l0;
+                P.nodes.aux[c * 4 + 1] = o.child_w0;
+                P.nodes.aux[c * 4 + 2] = w == 0 ? o.Et.re : o.Er.re;
+                P.nodes.aux[c * 4 + 3] = w == 0 ? o.Et.im : o.Er.im;
+            }
+            const int32_t fl = (1 < P.r_max) ? 0 : F_DEAD;
+            // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
+            write_next(slot, o.nc, o.nw, o.nd, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
+            write_next(slot + 1, o.rc, o.rw, o.rd, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
+        } else {
+            atomicAdd(&P.ctr->overflow, 1ull);
+        }
+    }
+    unsigned int c = calls;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane_id() == 0 && c) atomicAdd(&P.ctr->calls, (unsigned long long)c);
+}
+
 // ------------------------------------------------------------------ small helper kernels
 template <int KIND>
 __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_idx, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max) {
@@ -324,11 +496,26 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int64_t cap = c0.cap;
-    for (int p = 0; p < 6; ++p) c0.d[p * cap + j] = planes[p * n + j];
-    c0.d[6 * cap + j] = planes[7 * n + j];
-    if (KIND == BMO_BEAM_POLARIZED)
-        for (int p = 0; p < 6; ++p) c0.d[(11 + p) * cap + j] = planes[(8 + p) * n + j];
-    c0.d[L::OPL * cap + j] = 0.0;
+    double lam;
+    if (KIND == BMO_BEAM_GAUSSIAN) {
+        for (int b = 0; b < 3; ++b) {
+            for (int p = 0; p < 6; ++p) c0.d[(11 * b + p) * cap + j] = planes[(6 * b + p) * n + j];
+            c0.d[(11 * b + 6) * cap + j] = planes[19 * n + j];
+        }
+        for (int p = 33; p < 38; ++p) c0.d[p * cap + j] = 0.0;
+        lam = planes[18 * n + j];
+        nodes.aux[j * 4 + 0] = 0.0;
+        nodes.aux[j * 4 + 1] = planes[20 * n + j];
+        nodes.aux[j * 4 + 2] = planes[21 * n + j];
+        nodes.aux[j * 4 + 3] = planes[22 * n + j];
+    } else {
+        for (int p = 0; p < 6; ++p) c0.d[p * cap + j] = planes[p * n + j];
+        c0.d[6 * cap + j] = planes[7 * n + j];
+        if (KIND == BMO_BEAM_POLARIZED)
+            for (int p = 0; p < 6; ++p) c0.d[(11 + p) * cap + j] = planes[(8 + p) * n + j];
+        c0.d[L::OPL * cap + j] = 0.0;
+        lam = planes[6 * n + j];
+    }
     c0.i[I_NODE * cap + j] = (int32_t)j;
     c0.i[I_K * cap + j] = 0;
     c0.i[I_HOBJ * cap + j] = -1;
@@ -339,7 +526,7 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
     nodes.nseg[j] = 1;
     nodes.status[j] = 0;
     nodes.li[j] = lambda_idx[j];
-    nodes.lambda[j] = planes[6 * n + j];
+    nodes.lambda[j] = lam;
     nodes.hit_det[j] = -1;
     nodes.key[j] = ((unsigned long long)j) << 32;
 }
@@ -349,13 +536,13 @@ __global__ void iota_kernel(int32_t* a, int64_t n) {
     if (j < n) a[j] = (int32_t)j;
 }
 // flags[d*n + i] = 1 if canonical node i recorded a hit on detector d
-__global__ void hit_flags_kernel(const int32_t* order, const int32_t* hit_det, int64_t n, int32_t n_det, int32_t* flags) {
+__global__ void hit_flags_kernel(const int32_t* order, const int32_t* hit_det, int64_t n, int32_t n_det, int32_t nsub, int32_t* flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t d = hit_det[order[i]];
-    for (int32_t q = 0; q < n_det; ++q) flags[(int64_t)q * n + i] = (q == d) ? 1 : 0;
+    for (int32_t q = 0; q < n_det; ++q) flags[(int64_t)q * n + i] = (q == d) ? nsub : 0;
 }
-__global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, const double* hit, int64_t n, const int32_t* flags,
+__global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, const double* hit, int64_t n, int32_t nsub,
                                   const int32_t* offs, double* out, int32_t* out_node) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -363,8 +550,10 @@ __global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, 
     const int32_t d = hit_det[nd];
     if (d < 0) return;
     const int64_t pos = offs[(int64_t)d * n + i];
-    for (int c = 0; c < 9; ++c) out[pos * 9 + c] = hit[(int64_t)nd * 9 + c];
-    out_node[pos] = (int32_t)i;
+    for (int sub = 0; sub < nsub; ++sub) {
+        for (int c = 0; c < 9; ++c) out[(pos + sub) * 9 + c] = hit[((int64_t)nd * nsub + sub) * 9 + c];
+        out_node[pos + sub] = (int32_t)i;
+    }
 }
 
 // ------------------------------------------------------------------ host-side objects
@@ -490,7 +679,7 @@ struct bmo_trace_result {
     // device state
     std::vector<std::unique_ptr<DevBuf>> arena;  // chunk storage
     std::vector<Chunk> chunks;
-    DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, order, det_data, det_node;
+    DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, n_aux, order, det_data, det_node;
     std::vector<int64_t> det_count, det_offset;
     // host views (filled by bmo_result_view)
     bool viewed = false;
@@ -550,6 +739,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     hipEvent_t ev_a = ctx.ev[0], ev_b = ctx.ev[1], ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
     HIP_TRY(hipEventRecord(ev_t0, stream));
 
+    const int nsub = KIND == BMO_BEAM_GAUSSIAN ? 3 : 1;
     // node arrays: roots + room for children (grown on demand)
     int64_t node_cap = has_split ? 3 * n + 64 : n;
     auto alloc_nodes = [&](int64_t cap) -> int {
@@ -562,7 +752,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if ((r = R->n_hitdet.alloc(cap * 4))) return r;
         if ((r = R->n_key.alloc(cap * 8))) return r;
         if ((r = R->n_lambda.alloc(cap * 8))) return r;
-        if ((r = R->n_hit.alloc(cap * 72))) return r;
+        if ((r = R->n_hit.alloc(cap * 72 * nsub))) return r;
+        if ((r = R->n_aux.alloc(cap * 32))) return r;
         return BMO_OK;
     };
     if ((rc = alloc_nodes(node_cap))) return rc;
@@ -577,7 +768,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         a.key = (unsigned long long*)R->n_key.p;
         a.lambda = (double*)R->n_lambda.p;
         a.hit = (double*)R->n_hit.p;
+        a.aux = (double*)R->n_aux.p;
         a.cap = node_cap;
+        a.hit_sub = nsub;
         return a;
     };
     auto grow_nodes = [&](int64_t need) -> int {
@@ -596,7 +789,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         };
         int r;
         if ((r = mv(R->n_root, 4)) || (r = mv(R->n_parent, 4)) || (r = mv(R->n_nseg, 4)) || (r = mv(R->n_status, 4)) || (r = mv(R->n_li, 4)) ||
-            (r = mv(R->n_hitdet, 4)) || (r = mv(R->n_key, 8)) || (r = mv(R->n_lambda, 8)) || (r = mv(R->n_hit, 72)))
+            (r = mv(R->n_hitdet, 4)) || (r = mv(R->n_key, 8)) || (r = mv(R->n_lambda, 8)) || (r = mv(R->n_hit, 72 * (size_t)nsub)) || (r = mv(R->n_aux, 32)))
             return r;
         node_cap = ncap;
         return BMO_OK;
@@ -653,8 +846,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         DBG("init kernel done");
     }
     const size_t lds_bytes = use_lds ? blob_bytes : 0;
-    if (lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (lds_bytes > 48 * 1024) {
+        if constexpr (KIND == BMO_BEAM_GAUSSIAN)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_gauss), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        else
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
 
     int64_t n_nodes = n;
     double kernel_ms = 0;
@@ -675,7 +872,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.r_max = opts->r_max;
         DBG("step %d launching m=%lld", steps, (long long)m);
         HIP_TRY(hipEventRecord(ev_a, stream));
-        hipLaunchKernelGGL((step_kernel<KIND>), dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
+        if constexpr (KIND == BMO_BEAM_GAUSSIAN)
+            hipLaunchKernelGGL(step_kernel_gauss, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
+        else
+            hipLaunchKernelGGL((step_kernel<KIND>), dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ev_b, stream));
         HIP_TRY(hipMemcpyAsync(&h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -730,7 +930,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         const int64_t tot = (int64_t)nd * n_nodes;
         if ((rc = flags.alloc((size_t)tot * 4)) || (rc = offs.alloc((size_t)tot * 4))) return rc;
         hipLaunchKernelGGL(hit_flags_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p, n_nodes, nd,
-                           (int32_t*)flags.p);
+                           nsub, (int32_t*)flags.p);
         size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
@@ -752,7 +952,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if ((rc = R->det_data.alloc((size_t)std::max<int64_t>(total, 1) * 72)) || (rc = R->det_node.alloc((size_t)std::max<int64_t>(total, 1) * 4)))
             return rc;
         hipLaunchKernelGGL(hit_gather_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
-                           (const double*)R->n_hit.p, n_nodes, (const int32_t*)flags.p, (const int32_t*)offs.p, (double*)R->det_data.p,
+                           (const double*)R->n_hit.p, n_nodes, nsub, (const int32_t*)offs.p, (double*)R->det_data.p,
                            (int32_t*)R->det_node.p);
         HIP_TRY(hipStreamSynchronize(stream));
     }
@@ -882,7 +1082,6 @@ int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, 
     if (in->kind != BMO_BEAM_RAY && in->kind != BMO_BEAM_POLARIZED && in->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bad beam kind");
     const int want = in->kind == BMO_BEAM_RAY ? BMO_PLANES_RAY : (in->kind == BMO_BEAM_POLARIZED ? BMO_PLANES_POLARIZED : BMO_PLANES_GAUSSIAN);
     if (in->n_planes != want || in->n < 0) return fail(BMO_ERR_INVALID, "bad plane count");
-    if (in->kind == BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_UNSUPPORTED, "GaussianBeamlet tracing is not built yet");
     if (in->n > 0x7fffffff / 4) return fail(BMO_ERR_INVALID, "batch too large for one device (shard it)");
     for (int64_t i = 0; i < in->n; ++i)
         if (in->lambda_idx[i] < 0 || in->lambda_idx[i] >= scene->hdr.n_lambda) return fail(BMO_ERR_INVALID, "lambda_idx out of range");
@@ -917,6 +1116,7 @@ int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_
     int rc;
     if (batch->kind == BMO_BEAM_RAY) rc = run_trace<BMO_BEAM_RAY>(scene, batch, opts, R.get());
     else if (batch->kind == BMO_BEAM_POLARIZED) rc = run_trace<BMO_BEAM_POLARIZED>(scene, batch, opts, R.get());
+    else if (batch->kind == BMO_BEAM_GAUSSIAN) rc = run_trace<BMO_BEAM_GAUSSIAN>(scene, batch, opts, R.get());
     else return fail(BMO_ERR_UNSUPPORTED, "beam kind not built yet");
     if (rc) return rc;
     *out = R.release();
@@ -968,6 +1168,8 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
         if ((rc = dl(root, r->n_root.p, nn)) || (rc = dl(parent, r->n_parent.p, nn)) || (rc = dl(nseg, r->n_nseg.p, nn)) ||
             (rc = dl(status, r->n_status.p, nn)) || (rc = dl(order, r->order.p, nn)) || (rc = dl(lambda, r->n_lambda.p, nn)))
             return rc;
+        std::vector<double> aux;
+        if (r->kind == BMO_BEAM_GAUSSIAN && (rc = dl(aux, r->n_aux.p, (size_t)nn * 4))) return rc;
         std::vector<int32_t> rank(nn);
         for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int32_t)i;
         r->h_root.resize(nn);
@@ -985,7 +1187,14 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
             r->h_nseg[i] = nseg[nd];
             r->h_status[i] = status[nd];
             r->h_first_rec[i] = (int32_t)acc;
-            r->h_aux[4 * i] = lambda[nd];
+            if (r->kind == BMO_BEAM_GAUSSIAN) {
+                r->h_aux[4 * i + 0] = aux[4 * (size_t)nd + 1];
+                r->h_aux[4 * i + 1] = aux[4 * (size_t)nd + 2];
+                r->h_aux[4 * i + 2] = aux[4 * (size_t)nd + 3];
+                r->h_aux[4 * i + 3] = lambda[nd];
+            } else {
+                r->h_aux[4 * i] = lambda[nd];
+            }
             acc += nseg[nd];
         }
         for (int64_t i = 0; i < nn; ++i) {

@@ -672,7 +672,8 @@ BMO_HD d3 hit_point(const RayS& r, double t) { return axpy3(r.pos, t, r.dir); }
 //   detectors Spotdetector.jl:50-61, PSFDetector.jl:77-89     polarizer PolarizationFilter.jl:31-48
 // `opl_before` = optical path length of the beam (incl. parents) up to the START of this segment.
 template <int KIND>
-BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, double lambda, double opl_before, StepOut& o) {
+BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, double lambda, double opl_before, StepOut& o,
+                     int ent_override = -1) {
     const bmo_object& ob = S.objects[X.obj];
     o.outcome = OUT_STOP;
     o.hint_obj = o.hint_shape = -1;
@@ -837,7 +838,9 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
         if (split_mode == 1) {  // PlateBeamsplitter.jl:203-225
             const double n_opt = n_medium(S, ob.medium[0], li);
             const bool ent = dot3(ray.dir, X.n) < 0;
-            const double nt = ent ? n_opt : 1.0, nr = ent ? 1.0 : n_opt;
+            // a GaussianBeamlet picks n_t / n_r from the CHIEF ray's isentering (PlateBeamsplitter.jl:245-262)
+            const bool ent_n = ent_override < 0 ? ent : (ent_override != 0);
+            const double nt = ent_n ? n_opt : 1.0, nr = ent_n ? 1.0 : n_opt;
             d3 nml = X.n;  // refraction3d(ray, n2) AbstractRay.jl:244-253
             if (!ent) nml = {nml.x * -1, nml.y * -1, nml.z * -1};
             d3 nd;
@@ -913,6 +916,167 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
         o.outcome = OUT_CONTINUE;
         return;
     }
+}
+
+// ------------------------------------------------------------------ GaussianBeamlet (Gaussian.jl, System.jl:274-318)
+// A GaussianBeamlet is three geometric rays (chief, waist, divergence) traced in lock-step; one lane carries
+// all three.  Beam parameters are reconstructed only when a splitter spawns children (gauss_parameters).
+struct GaussIn {
+    RayS c, w, d;
+    int32_t hint_obj, hint_shape;
+    double lenA;   // sum of the chief's own segment lengths before this one, folded from 0 (length_rays, Beam.jl:160-169)
+    double lenB;   // length(parent chief) + the same sum, folded in that order (point_on_beam's `temp`, Beam.jl:180-190)
+    double l0;     // length(parent chief beam) (0 for roots)
+    double oplC, oplW, oplD;  // optical path lengths up to this segment's start (chief incl. parents; waist/div own rays only)
+    double lambda, w0;
+    cx E0;
+    int li;
+};
+struct GaussOut {
+    int outcome, status;
+    Hit Xc, Xw, Xd;
+    int32_t hint_obj, hint_shape;
+    RayS nc, nw, nd;  // next segment, or transmitted child
+    RayS rc, rw, rd;  // reflected child
+    int det_slot, n_det;
+    double det[27];
+    double child_w0, child_l0;
+    cx Et, Er;
+    double oplC, oplW, oplD, lenA, lenB;  // accumulators for the next segment
+};
+
+// line_plane_distance3d LinearAlgebraUtils.jl:127-136 (NaN stands for `nothing`)
+BMO_HD double line_plane_distance3d(const d3& pp, const d3& pn, const d3& lp, const d3& ld) {
+    double denom = dot3(pn, ld);
+    if (fabs(denom) > 1e-6) return dot3(sub3(pp, lp), pn) / denom;
+    return kinf() - kinf();
+}
+
+// gauss_parameters(gauss, length(gauss)) Gaussian.jl:298-353, evaluated at the splitter hit (last segment);
+// point_on_beam (Beam.jl:177-205) reduces to p0 = pos + (t - temp)*dir on the last chief segment.  Returns w0.
+BMO_HD double gauss_w0_at(const GaussIn& g, double t_total, double temp) {
+    const double b = t_total - temp;
+    const d3 p0 = axpy3(g.c.pos, b, g.c.dir);
+    double y_d, m_d, y_w, m_w;
+    {
+        double il = line_plane_distance3d(p0, g.c.dir, g.d.pos, g.d.dir);
+        d3 y0{g.d.pos.x + il * g.d.dir.x - p0.x, g.d.pos.y + il * g.d.dir.y - p0.y, g.d.pos.z + il * g.d.dir.z - p0.z};
+        y_d = norm3(y0);
+        y0 = {y0.x / y_d, y0.y / y_d, y0.z / y_d};
+        m_d = tan(3.141592653589793 / 2 - angle3d(y0, g.d.dir));
+    }
+    {
+        double il = line_plane_distance3d(p0, g.c.dir, g.w.pos, g.w.dir);
+        d3 y0{g.w.pos.x + il * g.w.dir.x - p0.x, g.w.pos.y + il * g.w.dir.y - p0.y, g.w.pos.z + il * g.w.dir.z - p0.z};
+        y_w = norm3(y0);
+        y0 = {y0.x / y_w, y0.y / y_w, y0.z / y_w};
+        m_w = tan(3.141592653589793 / 2 - angle3d(y0, g.w.dir));
+    }
+    const double n = g.c.n;
+    double H = fabs(n * (y_w * m_d - y_d * m_w));
+    if (!isapprox(H, g.lambda / 3.141592653589793, 1e-6)) H = g.lambda / 3.141592653589793;
+    const double F = sqrt(m_d * m_d + m_w * m_w);
+    const double w = sqrt(y_d * y_d + y_w * y_w);
+    double w0 = H / (n * F);
+    if (isnan_(w0)) w0 = w;
+    return w0;
+}
+
+BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls) {
+    o.outcome = OUT_MISS;
+    o.status = 0;
+    o.hint_obj = o.hint_shape = -1;
+    o.det_slot = -1;
+    o.n_det = 0;
+    o.Xc = o.Xw = o.Xd = no_hit();
+    // chief, waist, divergence in that order; stop at the first ray without intersection (System.jl:283-296)
+    bool all_hit = true;
+    BMO_NOUNROLL
+    for (int r = 0; r < 3; ++r) {
+        const RayS& ray = r == 0 ? g.c : (r == 1 ? g.w : g.d);
+        Hit X = tracing_step(S, ray.pos, ray.dir, g.hint_obj, g.hint_shape, calls);
+        if (r == 0) o.Xc = X;
+        else if (r == 1) o.Xw = X;
+        else o.Xd = X;
+        if (X.shape < 0) {
+            all_hit = false;
+            break;
+        }
+    }
+    if (!all_hit) {
+        o.status = BMO_NODE_MISS;
+        return;
+    }
+    if (!(o.Xc.shape == o.Xw.shape && o.Xw.shape == o.Xd.shape)) {  // _beams_hits_same_shape Gaussian.jl:171-180
+        o.Xc = o.Xw = o.Xd = no_hit();
+        o.status = BMO_NODE_GAUSS_DIVERGED;
+        return;
+    }
+    const int32_t oid = o.Xc.obj;
+    const bmo_object& ob = S.objects[oid];
+    const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && o.Xc.shape == ob.shape[1]) ||
+                         (ob.kind == BMO_OBJ_CUBE_BS && o.Xc.shape == ob.shape[2]);
+    // every sub-beam interacts with the object found by the CHIEF ray (System.jl:306-309, Gaussian.jl:124-135)
+    bool all_continue = true;
+    BMO_NOUNROLL
+    for (int r = 0; r < 3; ++r) {
+        const RayS& ray = r == 0 ? g.c : (r == 1 ? g.w : g.d);
+        Hit X = r == 0 ? o.Xc : (r == 1 ? o.Xw : o.Xd);
+        X.obj = oid;
+        const double opl = r == 0 ? g.oplC : (r == 1 ? g.oplW : g.oplD);
+        StepOut so;
+        so.status = 0;
+        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, dot3(g.c.dir, o.Xc.n) < 0 ? 1 : 0);
+        o.status |= so.status;
+        if (r == 0) {
+            o.nc = so.next;
+            o.rc = so.refl;
+            o.hint_obj = so.hint_obj;
+            o.hint_shape = so.hint_shape;
+        } else if (r == 1) {
+            o.nw = so.next;
+            o.rw = so.refl;
+        } else {
+            o.nd = so.next;
+            o.rd = so.refl;
+        }
+        if (so.det_slot >= 0) {
+            o.det_slot = so.det_slot;
+            for (int c = 0; c < 9; ++c) {
+                if (r == 0) o.det[c] = so.det[c];
+                else if (r == 1) o.det[9 + c] = so.det[c];
+                else o.det[18 + c] = so.det[c];
+            }
+            o.n_det = r + 1;
+        }
+        const int want = coating ? OUT_SPLIT : OUT_CONTINUE;
+        if (so.outcome != want) all_continue = false;
+    }
+    o.oplC = g.oplC + o.Xc.t * g.c.n;
+    o.oplW = g.oplW + o.Xw.t * g.w.n;
+    o.oplD = g.oplD + o.Xd.t * g.d.n;
+    o.lenA = g.lenA + o.Xc.t;
+    o.lenB = g.lenB + o.Xc.t;
+    if (!all_continue) {
+        o.outcome = OUT_STOP;
+        return;
+    }
+    if (!coating) {
+        o.outcome = OUT_CONTINUE;
+        return;
+    }
+    // splitter: ThinBeamsplitter.jl:117-168 (+ PlateBeamsplitter.jl:230-275, CubeBeamsplitter.jl:94-121 via interact's split modes)
+    const double t_total = (g.lenA + o.Xc.t) + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
+    const double w0 = gauss_w0_at(g, t_total, g.lenB);
+    o.child_w0 = w0;
+    o.child_l0 = t_total;
+    const double ratio = g.w0 / w0;
+    o.Et = cmulr(rmul(ob.transmittance, g.E0), ratio);
+    o.Er = cmulr(rmul(ob.reflectance, g.E0), ratio);
+    const double df = dot3(g.c.dir, o.Xc.n);
+    const cx ph = df < 0 ? cx{-1.0, 1.2246467991473532e-16} : cx{1.0, 0.0};  // exp(im*π) | exp(im*0)
+    o.Er = cmul(o.Er, ph);
+    o.outcome = OUT_SPLIT;
 }
 
 }  // namespace bmo

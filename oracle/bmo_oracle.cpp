@@ -722,7 +722,7 @@ Inter interact_beam(Ctx& C, Node& node, Beam& beam, const Ray& ray) {
         case BMO_OBJ_MIRROR: return interact_mirror(C, ray, node);
         case BMO_OBJ_REFRACTIVE: return interact_refractive(C, oid, o.medium[0], ray, node, o.shape[0]);
         case BMO_OBJ_DOUBLET: {  // DoubletLenses.jl:66-76 (Ray only)
-            if (C.kind != BMO_BEAM_RAY) return Inter{};
+            if (C.kind == BMO_BEAM_POLARIZED) return Inter{};  // Gaussian sub-beams are Beam{T,Ray{T}}: the Ray method applies
             if (ray.isect.shape == o.shape[0]) {
                 Inter i = interact_refractive(C, oid, o.medium[0], ray, node, o.shape[0]);
                 if (i.some) i.hint = Hint{true, oid, o.shape[1]};

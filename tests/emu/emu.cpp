@@ -217,6 +217,236 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     v->det_node = R.det_node.data();
     v->det_data = R.det.data();
 }
+
+// ---- GaussianBeamlet schedule (mirrors step_kernel_gauss) ----------------------------------------------------
+struct GRec {
+    GaussIn g;
+    GaussOut o;
+    int node, k, flags;
+};
+struct GNode {
+    int root, parent, nseg, status, li, hit_det;
+    unsigned long long key;
+    double lambda, l0, w0;
+    cx E0;
+    double hit[27];
+};
+void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v) {
+    SceneView S;
+    S.objects = d->objects;
+    S.shapes = d->shapes;
+    S.children = d->children;
+    S.tris = d->tris;
+    S.n_table = d->n_table;
+    S.n_objects = d->n_objects;
+    S.n_lambda = d->n_lambda;
+    S.eps_srf = d->eps_srf;
+    S.eps_ray = d->eps_ray;
+    S.eps_ins = d->eps_ins;
+    S.mt_keps = d->mt_keps;
+    S.mt_leps = d->mt_leps;
+    S.grad_h = d->grad_h;
+    S.march_iters = d->march_iters;
+    const int64_t n = in->n;
+    const double* P = in->planes;
+    std::vector<GNode> nodes(n);
+    std::vector<GRec> cur(n), all;
+    auto mk = [&](int base, int64_t j, double nn) {
+        RayS r;
+        r.pos = {P[(base + 0) * n + j], P[(base + 1) * n + j], P[(base + 2) * n + j]};
+        r.dir = {P[(base + 3) * n + j], P[(base + 4) * n + j], P[(base + 5) * n + j]};
+        r.n = nn;
+        return r;
+    };
+    for (int64_t j = 0; j < n; ++j) {
+        GRec& r = cur[j];
+        double nn = P[19 * n + j];
+        r.g.c = mk(0, j, nn);
+        r.g.w = mk(6, j, nn);
+        r.g.d = mk(12, j, nn);
+        r.g.hint_obj = r.g.hint_shape = -1;
+        r.g.lenA = r.g.lenB = r.g.l0 = r.g.oplC = r.g.oplW = r.g.oplD = 0.0;
+        r.g.lambda = P[18 * n + j];
+        r.g.w0 = P[20 * n + j];
+        r.g.E0 = {P[21 * n + j], P[22 * n + j]};
+        r.g.li = in->lambda_idx[j];
+        r.node = (int)j;
+        r.k = 0;
+        r.flags = (1 < opts->r_max) ? 0 : 1;
+        GNode nd{};
+        nd.root = (int)j;
+        nd.parent = -1;
+        nd.nseg = 1;
+        nd.li = r.g.li;
+        nd.hit_det = -1;
+        nd.key = ((unsigned long long)j) << 32;
+        nd.lambda = r.g.lambda;
+        nd.w0 = r.g.w0;
+        nd.E0 = r.g.E0;
+        nodes[j] = nd;
+    }
+    unsigned long long calls = 0;
+    int steps = 0;
+    while (!cur.empty()) {
+        std::vector<GRec> surv, kids;
+        for (GRec& r : cur) {
+            uint32_t c = 0;
+            int status = 0;
+            bool survive = false;
+            r.o.Xc = r.o.Xw = r.o.Xd = no_hit();
+            r.o.outcome = OUT_MISS;
+            r.o.det_slot = -1;
+            if (r.flags & 1) status = BMO_NODE_RMAX;
+            else {
+                gauss_step(S, r.g, r.o, c);
+                status = r.o.status;
+                if (r.o.outcome == OUT_CONTINUE) survive = true;
+                else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                else if (r.o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
+            }
+            calls += c;
+            if (!survive) {
+                nodes[r.node].nseg = r.k + 1;
+                nodes[r.node].status = status;
+                if (r.o.det_slot >= 0 && !(r.flags & 1)) {
+                    nodes[r.node].hit_det = r.o.det_slot;
+                    std::memcpy(nodes[r.node].hit, r.o.det, sizeof r.o.det);
+                }
+            }
+            auto next = [&](const RayS& c1, const RayS& w1, const RayS& d1, int node, int k, int ho, int hs, int fl, double lenA, double lenB,
+                            double oplC, double oplW, double oplD, const GNode& nd) {
+                GRec q;
+                q.g = r.g;
+                q.g.c = c1;
+                q.g.w = w1;
+                q.g.d = d1;
+                q.g.hint_obj = ho;
+                q.g.hint_shape = hs;
+                q.g.lenA = lenA;
+                q.g.lenB = lenB;
+                q.g.oplC = oplC;
+                q.g.oplW = oplW;
+                q.g.oplD = oplD;
+                q.g.l0 = nd.l0;
+                q.g.w0 = nd.w0;
+                q.g.E0 = nd.E0;
+                q.node = node;
+                q.k = k;
+                q.flags = fl;
+                return q;
+            };
+            if (survive)
+                surv.push_back(next(r.o.nc, r.o.nw, r.o.nd, r.node, r.k + 1, r.o.hint_obj, r.o.hint_shape, (r.k + 2 < opts->r_max) ? 0 : 1, r.o.lenA,
+                                    r.o.lenB, r.o.oplC, r.o.oplW, r.o.oplD, nodes[r.node]));
+            if (!(r.flags & 1) && r.o.outcome == OUT_SPLIT) {
+                unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
+                for (int w = 0; w < 2; ++w) {
+                    GNode c2{};
+                    c2.root = (int)root;
+                    c2.parent = r.node;
+                    c2.nseg = 1;
+                    c2.li = r.g.li;
+                    c2.hit_det = -1;
+                    c2.key = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                    c2.lambda = r.g.lambda;
+                    c2.l0 = r.o.child_l0;
+                    c2.w0 = r.o.child_w0;
+                    c2.E0 = w == 0 ? r.o.Et : r.o.Er;
+                    nodes.push_back(c2);
+                    const int fl = (1 < opts->r_max) ? 0 : 1;
+                    if (w == 0) kids.push_back(next(r.o.nc, r.o.nw, r.o.nd, (int)nodes.size() - 1, 0, -1, -1, fl, 0.0, r.o.child_l0, r.o.oplC, 0.0, 0.0, c2));
+                    else kids.push_back(next(r.o.rc, r.o.rw, r.o.rd, (int)nodes.size() - 1, 0, -1, -1, fl, 0.0, r.o.child_l0, r.o.oplC, 0.0, 0.0, c2));
+                }
+            }
+        }
+        all.insert(all.end(), cur.begin(), cur.end());
+        cur = surv;
+        cur.insert(cur.end(), kids.begin(), kids.end());
+        steps += 1;
+    }
+    const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
+    std::vector<int> order(nn), rank(nn);
+    for (int64_t i = 0; i < nn; ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].key < nodes[b].key; });
+    for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int)i;
+    const int PL = 33;
+    R.root.resize(nn);
+    R.parent.resize(nn);
+    R.first_child.assign(nn, -1);
+    R.first_rec.resize(nn);
+    R.nseg.resize(nn);
+    R.status.resize(nn);
+    R.aux.assign(nn * 4, 0.0);
+    int64_t acc = 0;
+    for (int64_t i = 0; i < nn; ++i) {
+        const GNode& nd = nodes[order[i]];
+        R.root[i] = nd.root;
+        R.parent[i] = nd.parent < 0 ? -1 : rank[nd.parent];
+        R.nseg[i] = nd.nseg;
+        R.status[i] = nd.status;
+        R.first_rec[i] = (int32_t)acc;
+        R.aux[4 * i + 0] = nd.w0;
+        R.aux[4 * i + 1] = nd.E0.re;
+        R.aux[4 * i + 2] = nd.E0.im;
+        R.aux[4 * i + 3] = nd.lambda;
+        acc += nd.nseg;
+    }
+    for (int64_t i = 0; i < nn; ++i)
+        if (R.parent[i] >= 0 && (R.first_child[R.parent[i]] < 0 || i < R.first_child[R.parent[i]])) R.first_child[R.parent[i]] = (int32_t)i;
+    R.rec.assign((size_t)PL * nr, 0.0);
+    R.rec_obj.assign(nr, -1);
+    R.rec_shape.assign(nr, -1);
+    for (const GRec& r : all) {
+        int64_t dst = (int64_t)R.first_rec[rank[r.node]] + r.k;
+        const RayS* rs[3] = {&r.g.c, &r.g.w, &r.g.d};
+        const Hit* hs[3] = {&r.o.Xc, &r.o.Xw, &r.o.Xd};
+        for (int b = 0; b < 3; ++b) {
+            double vals[11] = {rs[b]->pos.x, rs[b]->pos.y, rs[b]->pos.z, rs[b]->dir.x, rs[b]->dir.y, rs[b]->dir.z, rs[b]->n,
+                               hs[b]->t, hs[b]->n.x, hs[b]->n.y, hs[b]->n.z};
+            for (int p2 = 0; p2 < 11; ++p2) R.rec[(size_t)(11 * b + p2) * nr + dst] = vals[p2];
+        }
+        R.rec_obj[dst] = r.o.Xc.obj;
+        R.rec_shape[dst] = r.o.Xc.shape;
+    }
+    const int ndet = d->n_detectors;
+    R.det_count.assign(ndet, 0);
+    R.det_offset.assign(ndet, 0);
+    for (int q = 0; q < ndet; ++q) {
+        R.det_offset[q] = (int64_t)R.det_node.size();
+        for (int64_t i = 0; i < nn; ++i) {
+            const GNode& nd = nodes[order[i]];
+            if (nd.hit_det != q) continue;
+            for (int sub = 0; sub < 3; ++sub) {
+                R.det_node.push_back((int32_t)i);
+                R.det.insert(R.det.end(), nd.hit + 9 * sub, nd.hit + 9 * sub + 9);
+            }
+        }
+        R.det_count[q] = (int64_t)R.det_node.size() - R.det_offset[q];
+    }
+    std::memset(v, 0, sizeof *v);
+    v->n_roots = n;
+    v->n_nodes = nn;
+    v->n_records = nr;
+    v->n_intersect_calls = (int64_t)calls;
+    v->n_steps = steps;
+    v->beam_kind = BMO_BEAM_GAUSSIAN;
+    v->rec_planes = PL;
+    v->n_detectors = ndet;
+    v->node_root = R.root.data();
+    v->node_parent = R.parent.data();
+    v->node_first_child = R.first_child.data();
+    v->node_first_rec = R.first_rec.data();
+    v->node_nseg = R.nseg.data();
+    v->node_status = R.status.data();
+    v->node_aux = R.aux.data();
+    v->rec_obj = R.rec_obj.data();
+    v->rec_shape = R.rec_shape.data();
+    v->rec = R.rec.data();
+    v->det_count = R.det_count.data();
+    v->det_offset = R.det_offset.data();
+    v->det_node = R.det_node.data();
+    v->det_data = R.det.data();
+}
 }  // namespace
 
 extern "C" {
@@ -224,6 +454,7 @@ int bmo_emu_trace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_tr
     auto* R = new ResultE();
     if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v);
     else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v);
+    else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v);
     else {
         delete R;
         return BMO_ERR_UNSUPPORTED;

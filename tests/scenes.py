@@ -117,3 +117,63 @@ def c2_scene():
 def c2_bundle(n, lam=1.064e-6):
     """Extended object 0.3 mm across at the miniscope's object plane, rays filling a 0.25 rad cone (NA ~ 0.25)."""
     return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, lam=lam, e1=[1, 0, 0], cone=0.25)
+
+
+# ------------------------------------------------------------------------------------ C4
+def c4_scene():
+    """Three singlets (bi-convex, meniscus, plano-convex => 6 refracting surfaces) + IntersectableObject end stop."""
+    l1 = bmo.SphericalLens(60 * mm, -60 * mm, 6 * mm, 25.4 * mm, 1.5)
+    l2 = bmo.SphericalLens(30 * mm, 60 * mm, 2.5 * mm, 25.4 * mm, 1.6)  # l0 <= 0 with same-sign radii => MeniscusLensSDF
+    assert isinstance(l2.shape, bmo.MeniscusLensSDF)
+    l3 = bmo.SphericalLens(math.inf, -40 * mm, 5 * mm, 25.4 * mm, 1.7)
+    bmo.translate3d(l2, [0, 15 * mm, 0])
+    bmo.translate3d(l3, [0, 30 * mm, 0])
+    stop = bmo.IntersectableObject(bmo.QuadraticFlatMesh(40 * mm))
+    bmo.translate3d(stop, [0, 60 * mm, 0])
+    for o in (l1, l2, l3):  # a small tilt so s/p bases are not degenerate everywhere
+        bmo.xrotate3d(o, math.radians(3))
+    return bmo.System([l1, l2, l3, stop]), dict(l1=l1, l2=l2, l3=l3, stop=stop)
+
+
+def polarized_bundle(n, center, direction, diameter, lam=1.064e-6, jitter=2e-3, e1=None, seed=SEED):
+    """disc_bundle + E0 = unit linear polarization at 45 deg in the (e1, e2) plane, made orthogonal to each ray's dir."""
+    b = disc_bundle(n, center, direction, diameter, lam, jitter, e1, seed)
+    d = bmo.linalg.normalize(np.asarray(direction, dtype=np.float64))
+    e1 = bmo.linalg.perpendicular(d) if e1 is None else np.asarray(e1, dtype=np.float64)
+    e2 = bmo.linalg.normalize(np.cross(d, e1))
+    dirs = b.planes[3:6].T
+    E = (e1 + e2)[None, :] / math.sqrt(2) * np.ones((n, 1))
+    for _ in range(3):  # Gram-Schmidt to 1e-16
+        E = E - (E * dirs).sum(axis=1)[:, None] * dirs
+    E = E / np.linalg.norm(E, axis=1)[:, None]
+    P = np.zeros((14, n))
+    P[:8] = b.planes
+    P[8:14:2] = E.T
+    return bmo.RayBundle(bmo.BEAM_POLARIZED, P)
+
+
+def c4_bundle(n):
+    return polarized_bundle(n, center=[0, -0.03, 0], direction=[0, 1, 0], diameter=0.8 * 25.4 * mm, e1=[1, 0, 0])
+
+
+# ------------------------------------------------------------------------------------ C3
+def gaussian_bundle(n, center, direction, diameter, lam=1.064e-6, w0=50e-6, support=(1.0, 0.0, 0.0), M2=1.0, P0=1e-3, z0=0.0, cone=None,
+                    jitter=2e-3, seed=SEED):
+    """N GaussianBeamlet(pos, dir, lam, w0; support) built like the reference constructor (Gaussian.jl:215-256), vectorised."""
+    b = disc_bundle(n, center, direction, diameter, lam, jitter, e1=support, seed=seed, cone=cone)
+    pos, d = b.planes[0:3].T, b.planes[3:6].T
+    s1 = bmo.linalg.normalize(np.asarray(support, dtype=np.float64))
+    tan_t = math.tan(M2 * lam / (math.pi * w0))
+    dd = d + s1[None, :] * tan_t
+    dd = dd / np.sqrt((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2])[:, None]
+    P = np.zeros((25, n))
+    P[0:3], P[3:6] = pos.T, d.T
+    P[6:9], P[9:12] = (pos + s1[None, :] * w0).T, d.T
+    P[12:15], P[15:18] = (pos + s1[None, :] * (-z0 * tan_t)).T, dd.T
+    P[18], P[19], P[20] = lam, 1.0, w0
+    P[21] = math.sqrt(2 * (2 * P0 / (math.pi * w0 ** 2)) * bmo.linalg.Z_vacuum)
+    return bmo.RayBundle(bmo.BEAM_GAUSSIAN, P)
+
+
+def c3_bundle(n):
+    return gaussian_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, w0=50e-6, support=(1.0, 0.0, 0.0), cone=0.1)
