@@ -133,6 +133,62 @@ class GaussianBeamlet:
     def rays(self):
         return self.chief.rays
 
+    def length(self):
+        return self.chief.length()
+
+
+def point_on_beam(beam, t):
+    """Beam.jl:177-205: point at geometric distance t along the beam (parents included) and its 1-based segment index."""
+    temp = 0.0 if beam.parent is None else beam.parent.length()
+    num = len(beam.rays)
+    for index, ray in enumerate(beam.rays, start=1):
+        if index == num:
+            break
+        temp += ray.length()
+        if t < temp:
+            b = temp - t
+            return ray.pos + (ray.length() - b) * ray.dir, index
+    ray = beam.rays[-1]
+    return ray.pos + (t - temp) * ray.dir, num
+
+
+def gauss_parameters(gauss, z):
+    """Gaussian.jl:298-353: (w, R, psi, w0) of a traced GaussianBeamlet at path length z (Arnaud / DeJager complex rays)."""
+    p0, index = point_on_beam(gauss.chief, z)
+    chief, div, waist = gauss.chief.rays[index - 1], gauss.divergence.rays[index - 1], gauss.waist.rays[index - 1]
+
+    def height_slope(r):
+        denom = np.dot(chief.dir, r.dir)
+        il = np.dot(p0 - r.pos, chief.dir) / denom if abs(denom) > 1e-6 else math.nan
+        y0 = r.pos + il * r.dir - p0
+        y = math.sqrt(np.dot(y0, y0))
+        with np.errstate(all="ignore"):
+            y0 = y0 / y
+            arg = max(-1.0, min(1.0, np.dot(y0, r.dir) / (np.linalg.norm(y0) * np.linalg.norm(r.dir)))) if y > 0 else math.nan
+        return y, math.tan(math.pi / 2 - math.acos(arg)) if arg == arg else math.nan
+
+    y_d, m_d = height_slope(div)
+    y_w, m_w = height_slope(waist)
+    n = chief.n
+    H = abs(n * (y_w * m_d - y_d * m_w))
+    lam = gauss.lam
+    if not abs(H - lam / math.pi) <= 1e-6:
+        H = lam / math.pi
+    E_kt = y_d * m_d + y_w * m_w
+    F_kt = math.sqrt(m_d ** 2 + m_w ** 2)
+    w = math.sqrt(y_d ** 2 + y_w ** 2)
+    with np.errstate(all="ignore"):
+        R = np.float64(E_kt) / np.float64(w ** 2)
+        zz = np.float64(E_kt) / np.float64(F_kt ** 2)
+        psi = -np.arctan2(1.0, np.sqrt(1 / (R * zz) - 1))
+        w0 = np.float64(H) / np.float64(n * F_kt)
+    R = 0.0 if np.isnan(R) else float(R)
+    psi = 0.0 if np.isnan(psi) else float(psi)
+    w0 = w if np.isnan(w0) else float(w0)
+    if R < 0:
+        psi = -psi
+    return w, R, psi, w0
+
 
 class BeamGroup:
     """AbstractBeamGroup (AbstractBeam.jl:99-124): `beams` is the batch."""

@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rays", type=int, default=1 << 20, help="root rays per GPU")
     ap.add_argument("--r-max", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="rays for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="rays for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,11 +69,20 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BMO_BENCH_BACKEND", "nccl")  # "gloo": rehearse the N > 1 path on a box with fewer GPUs
+        ndev = max(torch.cuda.device_count(), 1)
+        device_ord = local_rank % ndev
+        torch.cuda.set_device(device_ord)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_ord))
+        else:
+            dist.init_process_group(backend)
 
     import bmo_amd as bmo
-    from scenes import c2_bundle, c2_scene, disc_bundle, mm
+    from scenes import c2_bundle, c2_scene
+
+    if world > 1:
+        from bmo_amd import distributed as bd
 
     system, _ = c2_scene()
     n_local = args.rays
@@ -85,7 +94,7 @@ def main():
 
     bundle = shard_bundle(n_global, rank * n_local, (rank + 1) * n_local)  # contiguous shards keep reference order
     scene = bmo.CompiledScene(system, bundle.lambdas)
-    eng = bmo.Engine(scene, local_rank)
+    eng = bmo.Engine(scene, device_ord if world > 1 else 0)
     dev_batch = eng.upload(bundle)
     n_det = len(scene.detectors)
 
@@ -96,18 +105,11 @@ def main():
         gathered = None
         if world > 1:
             # all-gather of detector hits over xGMI: counts first, then padded buffers (hits are 9 x f64 records)
-            cnt = torch.tensor(counts, dtype=torch.int64, device="cuda")
-            allc = [torch.empty_like(cnt) for _ in range(world)]
-            dist.all_gather(allc, cnt)
-            allc = torch.stack(allc).cpu().numpy()
             gathered = []
             for s in range(n_det):
-                mx = int(allc[:, s].max())
-                buf = torch.zeros((max(mx, 1), 9), dtype=torch.float64, device="cuda")
-                eng.result_copy_hits(res, s, buf.data_ptr(), mx)
-                out = torch.empty((world, max(mx, 1), 9), dtype=torch.float64, device="cuda")
-                dist.all_gather_into_tensor(out, buf)
-                gathered.append((out, allc[:, s]))
+                local = torch.empty((counts[s], 9), dtype=torch.float64, device="cuda")
+                eng.result_copy_hits(res, s, local.data_ptr(), counts[s])
+                gathered.append(bd.all_gather_hits(local if backend == "nccl" else local.cpu()))  # hits in reference order
             torch.cuda.synchronize()
         view = None
         stats = dict(kernel_ms=kms, total_ms=tms, launches=nl, hits=counts)
@@ -136,7 +138,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -148,7 +150,7 @@ def main():
     hits = int(v.det_count.sum())
     eng.free_result(last)
     if world > 1:
-        agg = torch.tensor([calls, traced, hits, n_local], dtype=torch.float64, device="cuda")
+        agg = torch.tensor([calls, traced, hits, n_local], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(agg)
         calls_all, traced_all, hits_all, rays_all = (float(x) for x in agg.cpu())
     else:

@@ -175,5 +175,54 @@ def gaussian_bundle(n, center, direction, diameter, lam=1.064e-6, w0=50e-6, supp
     return bmo.RayBundle(bmo.BEAM_GAUSSIAN, P)
 
 
+# ------------------------------------------------------------------------------------ C5
+C5_X = (-12 * mm, 0.0, 12 * mm)
+
+
+def c5_scene():
+    """32 leaf objects: the miniscope train x3 (side by side in x), per train a 45 deg RoundPlanoMirror fold and a
+    RightAnglePrismMirror fold, one ThinBeamsplitter in the middle arm, two Spotdetectors, two IntersectableObject baffles."""
+    objs = []
+    y0 = 0.332 * mm
+    for x0 in C5_X:
+        grp = bmo.ObjectGroup(miniscope_objects())
+        bmo.translate3d(grp, [x0, 0, 0])
+        objs.append(grp)
+    for x0 in C5_X:
+        fold = bmo.RoundPlanoMirror(8 * mm, 2 * mm)
+        bmo.xrotate3d(fold, math.radians(45))
+        bmo.translate3d(fold, [x0, y0, 30 * mm])
+        objs.append(fold)
+    for x0 in C5_X:
+        prism = bmo.RightAnglePrismMirror(8 * mm, 8 * mm)
+        bmo.xrotate3d(prism, math.radians(225))
+        bmo.translate3d(prism, [x0, y0 - 10 * mm, 30 * mm])
+        objs.append(prism)
+    bs = bmo.ThinBeamsplitter(6 * mm)
+    bmo.xrotate3d(bs, math.radians(45))
+    bmo.translate3d(bs, [0, y0 - 10 * mm, 38 * mm])
+    det_t = bmo.Spotdetector(40 * mm)
+    bmo.xrotate3d(det_t, math.radians(90))
+    bmo.translate3d(det_t, [0, y0 - 10 * mm, 45 * mm])
+    det_r = bmo.Spotdetector(10 * mm)
+    bmo.translate3d(det_r, [0, y0 - 16 * mm, 38 * mm])
+    baffles = []
+    for x0 in (-6 * mm, 6 * mm):
+        b = bmo.IntersectableObject(bmo.RectangularFlatMesh(30 * mm, 30 * mm))
+        bmo.zrotate3d(b, math.radians(90))
+        bmo.translate3d(b, [x0, 0, 12 * mm])
+        baffles.append(b)
+    system = bmo.System(objs + [bs, det_t, det_r] + baffles)
+    return system, dict(bs=bs, det_t=det_t, det_r=det_r)
+
+
+def c5_bundle(n, lam=1.064e-6):
+    """Ray k feeds train k mod 3 (object plane of that train)."""
+    b = c2_bundle(n, lam)
+    P = b.planes.copy()
+    P[0] += np.array(C5_X)[np.arange(n) % 3]
+    return bmo.RayBundle(b.kind, P)
+
+
 def c3_bundle(n):
     return gaussian_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, w0=50e-6, support=(1.0, 0.0, 0.0), cone=0.1)

@@ -9,7 +9,7 @@ import pytest
 
 import bmo_amd as bmo
 from parity import compare
-from scenes import c1_bundle, c1_scene, c2_bundle, c2_scene, c3_bundle, c4_bundle, c4_scene
+from scenes import c1_bundle, c1_scene, c2_bundle, c2_scene, c3_bundle, c4_bundle, c4_scene, c5_bundle, c5_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -85,3 +85,10 @@ def test_c3_gaussian(engine_ok, oracle):
     assert got.rec_planes == 33 and got.n_nodes == 3 * got.n_roots
     # geometric planes of all three rays are libm-free and must be bit-exact
     assert np.array_equal(got.rec, ref.rec)
+
+
+def test_c5_32_elements(engine_ok, oracle):
+    system, _ = c5_scene()
+    got, ref = run_both(oracle, system, c5_bundle(1536))
+    compare(got, ref, 0.0, "c5")
+    assert got.det_count.sum() > 0

@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: world_size-2 gloo process group.  Each rank traces its contiguous shard (with the oracle here — the
+GPU engine is exercised by tests marked gpu), the detector hit buffers are all-gathered with the same
+`distributed.all_gather_hits` that bench.py uses over RCCL, and rank 0 checks that the concatenation equals the
+un-sharded solve bit for bit (reference push! order is preserved by contiguous shards)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ragged, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bmo_amd as bmo
+    import pyoracle
+    from bmo_amd import distributed as bd
+    from scenes import c2_bundle, c2_scene
+
+    system, _ = c2_scene()
+    full = c2_bundle(n)
+    if ragged:  # make some rays miss everything so shards have different hit counts (and one shard may have none)
+        full.planes[3:6, : n // 3] = np.array([[1.0], [0.0], [0.0]])
+    lo, hi = bd.shard_bounds(n, rank, world)
+    shard = bmo.RayBundle(full.kind, full.planes[:, lo:hi])
+    scene = bmo.CompiledScene(system, full.lambdas)
+    res = pyoracle.trace(scene, shard, 100, threads=2)
+    gathered = []
+    for slot in range(len(scene.detectors)):
+        hits, counts = bd.all_gather_hits(torch.from_numpy(res.detector_hits(slot).copy()))
+        gathered.append(hits.numpy())
+        assert int(counts.sum()) == hits.shape[0]
+    if rank == 0:
+        ref = pyoracle.trace(scene, full, 100, threads=2)
+        for slot in range(len(scene.detectors)):
+            assert np.array_equal(gathered[slot], ref.detector_hits(slot)), slot
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_sharded_hits_equal_unsharded(tmp_path, ragged):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), 96, ragged, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_shard_bounds_cover():
+    sys.path.insert(0, ROOT)
+    from bmo_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 1 << 20):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

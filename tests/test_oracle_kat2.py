@@ -1,0 +1,315 @@
+"""More known-answer tests of the reference (test/runtests.jl) against the CPU oracle: detectors, beam splitters,
+dummy objects, polarization ray tracing, polarizing filter, Gaussian beamlets.  Line ranges cite runtests.jl.
+
+Where the reference test re-solves an already traced beam (retracing, SURVEY f1 "next") a fresh beam is traced
+through the same moved system instead: the asserted end state is the same.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bmo_amd as bmo
+from test_oracle_kat import angle3d, approx
+
+mm = 1e-3
+
+
+# ------------------------------------------------------------------ Spotdetector (runtests.jl:1948-1973)
+def test_spotdetector_local_coordinates(oracle):
+    for x in np.linspace(-0.25, 0.25, 10):
+        sd = bmo.Spotdetector(1.0)
+        system = bmo.System([sd])
+        bmo.translate3d(sd, [0, 1, 0])
+        bmo.zrotate3d(sd, math.radians(45))
+        beam = bmo.Beam([x, 0, 0], [0, 1, 0], 1e-6)
+        oracle.solve_system(system, beam)
+        data = sd.data[-1]
+        ray = beam.rays[-1]
+        pos_ray = ray.pos + ray.intersection.t * ray.dir
+        pos_dta = sd.position() + sd.orientation()[:, 0] * data[0]
+        assert approx(pos_ray, pos_dta)
+    sd.empty()
+    assert len(sd.data) == 0
+
+
+# ------------------------------------------------------------------ plate / cube splitters (runtests.jl:2540-2652)
+@pytest.mark.parametrize("back", [False, True])
+def test_plate_beamsplitter(oracle, back):
+    N0 = 1.5
+    pbs = bmo.RectangularPlateBeamsplitter(36 * mm, 25 * mm, 1 * mm, lambda n: N0)
+    assert np.array_equal(pbs.position(), np.zeros(3))
+    bmo.zrotate3d(pbs, math.radians(45))
+    assert approx(pbs.orientation(), pbs.substrate.orientation())
+    if back:
+        bmo.zrotate3d(pbs, math.pi)
+    beam = bmo.Beam([0, -50 * mm, 0], [0, 1, 0], 1e-6)
+    oracle.solve_system(bmo.System([pbs]), beam)
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays
+    if not back:  # :2556-2566
+        assert (len(p), len(t), len(r)) == (1, 2, 1)
+        assert [x.n for x in p] == [1] and [x.n for x in t] == [N0, 1] and [x.n for x in r] == [1]
+        assert approx(p[0].dir, t[-1].dir) and approx(r[0].dir, [1, 0, 0])
+    else:  # :2576-2591
+        assert (len(p), len(t), len(r)) == (2, 1, 2)
+        assert [x.n for x in p] == [1, N0] and [x.n for x in t] == [1] and [x.n for x in r] == [N0, 1]
+        assert approx(p[0].dir, t[-1].dir) and approx(r[-1].dir, [1, 0, 0])
+
+
+@pytest.mark.parametrize("rot", [0.0, math.pi])
+def test_cube_beamsplitter(oracle, rot):
+    N0 = 1.5
+    cbs = bmo.CubeBeamsplitter(25e-3, lambda n: N0)
+    bmo.translate3d(cbs, [0, 50 * mm, 0])
+    if rot:
+        bmo.zrotate3d(cbs, rot)
+    beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
+    oracle.solve_system(bmo.System([cbs]), beam)
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays  # :2609-2616 and :2640-2651
+    assert (len(p), len(t), len(r)) == (2, 2, 2)
+    assert [x.n for x in p] == [1, N0] and [x.n for x in t] == [N0, 1] and [x.n for x in r] == [N0, 1]
+    assert approx(t[-1].dir, p[0].dir) and approx(r[-1].dir, [-1, 0, 0])
+
+
+def test_cube_beamsplitter_rotated_90(oracle):  # :2619-2631: exact equality of directions
+    cbs = bmo.CubeBeamsplitter(25e-3, lambda n: 1.5)
+    bmo.translate3d(cbs, [0, 50 * mm, 0])
+    bmo.zrotate3d(cbs, math.pi / 2)
+    beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
+    oracle.solve_system(bmo.System([cbs]), beam)
+    t = beam.children[0].rays
+    assert np.array_equal(t[-1].dir, beam.rays[0].dir) and np.array_equal(t[-1].dir, [0, 1, 0])
+
+
+# ------------------------------------------------------------------ dummy objects (runtests.jl:2655-2682)
+def test_intersectable_and_noninteractable(oracle):
+    cube = bmo.CubeMesh(1)
+    bmo.translate3d(cube, [-0.5, 0, -0.5])
+    bmo.translate3d(cube, [0, 5, 0])
+    beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
+    obj = bmo.IntersectableObject(cube)
+    oracle.solve_system(bmo.System([obj]), beam)
+    assert len(beam.rays) == 1
+    assert beam.rays[-1].intersection.object is obj and beam.rays[-1].intersection.shape is cube
+    beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
+    oracle.solve_system(bmo.System([bmo.NonInteractableObject(cube)]), beam)
+    assert len(beam.rays) == 1 and beam.rays[-1].intersection is None
+
+
+# ------------------------------------------------------------------ polarization (runtests.jl:2219-2436)
+def _P_times(oracle, in_dir, out_dir, nml, v):
+    import ctypes as C
+    import pyoracle
+
+    d = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    e = np.zeros(6)
+    e[0::2] = v
+    out = np.zeros(6)
+    j = np.array([-1.0, 0.0, 1.0, 0.0])  # SPBasis(-1, 0, 0, 1)
+    a, b, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (in_dir, out_dir, nml))
+    pyoracle.lib().bmo_cpu_global_E0(d(a), d(b), d(c), d(j), d(e), d(out))
+    return out[0::2] + 1j * out[1::2]
+
+
+def test_polarization_transforms(oracle):  # :2219-2241
+    n90 = np.array([1, 0, -1]) / math.sqrt(2)
+    assert approx(_P_times(oracle, [0, 0, 1], [1, 0, 0], n90, [1, 0, 0]).real, [0, 0, -1])
+    assert approx(_P_times(oracle, [0, 0, 1], [1, 0, 0], n90, [0, 0, 1]).real, [1, 0, 0])
+    assert approx(_P_times(oracle, [0, 0, 1], [0, 0, -1], [0, 0, -1.0], [1, 0, 0]).real, [-1, 0, 0])
+    assert approx(_P_times(oracle, [0, 0, 1], [0, 0, -1], [0, 0, -1.0], [0, 0, 1]).real, [0, 0, -1])
+
+
+def _three_mirrors(extra_y=0.0):
+    m1, m2, m3 = (bmo.SquarePlanoMirror2D(1.0) for _ in range(3))
+    bmo.translate3d(m2, [2, 0, 0])
+    bmo.translate3d(m3, [2, 2, 0])
+    bmo.zrotate3d(m1, math.radians(-90))
+    bmo.yrotate3d(m1, math.radians(45))
+    bmo.zrotate3d(m2, math.radians(45))
+    bmo.xrotate3d(m3, math.radians(135))
+    if extra_y:
+        bmo.translate3d(m3, [0, extra_y, 0])
+    return bmo.System([m1, m2, m3])
+
+
+def test_three_mirror_polarization(oracle):  # :2243-2288 (Yun et al. example)
+    beam = bmo.Beam(bmo.PolarizedRay([0.0, 0, -2], [0, 0, 1], 1000e-9, [1, 0, 0]))
+    oracle.solve_system(_three_mirrors(), beam)
+    E = [r.E0 for r in beam.rays]
+    assert approx(E[0].real, [1, 0, 0]) and approx(E[1].real, [0, 0, -1]) and approx(E[2].real, [0, 0, 1]) and approx(E[3].real, [0, -1, 0])
+    assert beam.length() == 6.0
+    beam = bmo.Beam(bmo.PolarizedRay([0.0, 0, -2], [0, 0, 1], 1000e-9, [0, 5, 0]))
+    oracle.solve_system(_three_mirrors(extra_y=2.0), beam)
+    E = [r.E0 for r in beam.rays]
+    assert approx(E[0].real, [0, 5, 0]) and approx(E[1].real, [0, -5, 0]) and approx(E[2].real, [5, 0, 0]) and approx(E[3].real, [-5, 0, 0])
+    assert beam.length() == 8.0
+
+
+def test_brewster_windows(oracle):  # :2290-2336
+    n = 1.5
+    thb = math.atan(n)
+    d = 0.1
+    rs, rp, ts, tp = oracle.fresnel_coefficients(thb, n)
+    Ts, Tp = 1 - abs(rs) ** 2, 1 - abs(rp) ** 2
+    lenses = []
+    for i in range(5):
+        s = bmo.CuboidMesh(1.0, d, 1.0)
+        l = bmo.Lens(s, lambda x: n)
+        bmo.translate3d(l, [-0.5, -d / 2, -0.5])
+        s.set_new_origin3d()
+        bmo.translate3d(l, [0, 0.5 * i, -i * d / 2])
+        lenses.append(l)
+    for l in lenses:
+        bmo.xrotate3d(l, -thb)
+    system = bmo.System(lenses)
+    E1 = bmo.beams.electric_field_from_intensity(1)
+    s_beam = bmo.Beam(bmo.PolarizedRay([-0.1, -1, 0], [0, 1.0, 0], 1000e-9, [E1, 0, 0]))
+    p_beam = bmo.Beam(bmo.PolarizedRay([+0.1, -1, 0], [0, 1.0, 0], 1000e-9, [0, 0, E1]))
+    oracle.solve_system(system, s_beam)
+    oracle.solve_system(system, p_beam)
+    assert s_beam.status & 256 == 0 and p_beam.status & 256 == 0  # no E0-orthogonality exception
+    Is = abs(s_beam.rays[-1].E0[0]) ** 2 / (2 * bmo.linalg.Z_vacuum)
+    Ip = abs(p_beam.rays[-1].E0[2]) ** 2 / (2 * bmo.linalg.Z_vacuum)
+    m = 10
+    assert approx(Is, Ts ** m) and approx(Ip, Tp ** m)
+
+
+def test_fresnel_rhomb(oracle):  # :2338-2361
+    n = 1.5
+    s1 = bmo.CuboidMesh(0.5, 1.25, 0.5, math.radians(53.3))
+    l1 = bmo.Lens(s1, lambda x: n)
+    bmo.translate3d(l1, [-0.25, 0, -0.25])
+    s1.set_new_origin3d()
+    bmo.yrotate3d(l1, math.radians(135))
+    beam = bmo.Beam(bmo.PolarizedRay([0, -1, 0], [0, 1.0, 0], 1000e-9, [0, 0, bmo.beams.electric_field_from_intensity(1)]))
+    oracle.solve_system(bmo.System([l1]), beam)
+    E = beam.rays[-1].E0
+    phi = np.angle(E[2]) - np.angle(E[0])
+    assert approx(phi, math.pi / 2)
+    assert abs(E[1]) < 2e-14
+
+
+def _mzi(E0):
+    inch = bmo.inch
+    m1, m2 = bmo.SquarePlanoMirror2D(inch), bmo.SquarePlanoMirror2D(inch)
+    b1, b2 = bmo.ThinBeamsplitter(inch, reflectance=0.5), bmo.ThinBeamsplitter(inch, reflectance=0.5)
+    bmo.translate3d(b2, [2 * inch, 2 * inch, 0])
+    bmo.translate3d(m1, [0, 2 * inch, 0])
+    bmo.translate3d(m2, [2 * inch, 0, 0])
+    bmo.zrotate3d(b1, math.radians(360 - 135))
+    bmo.zrotate3d(b2, math.radians(45))
+    bmo.zrotate3d(m1, math.radians(360 - 135))
+    bmo.zrotate3d(m2, math.radians(45))
+    return bmo.System([m1, m2, b1, b2]), bmo.Beam(bmo.PolarizedRay([0, -0.1, 0], [0.0, 1.0, 0], 1000e-9, E0))
+
+
+def test_mach_zehnder_phases(oracle):  # :2363-2436
+    system, beam = _mzi([0, 0, 1])
+    oracle.solve_system(system, beam)
+    c = beam.children
+    t, r, tr, rr = c[0].rays[0].E0, c[1].rays[0].E0, c[0].rays[1].E0, c[1].rays[1].E0
+    trt, trr, rrt, rrr = c[0].children[0].rays[0].E0, c[0].children[1].rays[0].E0, c[1].children[0].rays[0].E0, c[1].children[1].rays[0].E0
+    s = math.sqrt(2) / 2
+    assert approx(t[2].real, s) and approx(r[2].real, -s) and approx(tr[2].real, -s) and approx(rr[2].real, s)
+    assert approx(np.r_[trt.real, trt.imag], np.r_[rrr.real, rrr.imag]) and approx(np.r_[trr.real, trr.imag], np.r_[rrt.real, rrt.imag])
+    leaves = [x for ch in c for x in ch.children]
+    assert len(leaves) == 4
+    system, beam = _mzi([1, 0, 0])
+    oracle.solve_system(system, beam)
+    c = beam.children
+    t, r, tr, rr = c[0].rays[0].E0, c[1].rays[0].E0, c[0].rays[1].E0, c[1].rays[1].E0
+    assert approx(t[0].real, s) and approx(r[1].real, -s)
+    assert approx(np.r_[tr.real, tr.imag], np.r_[r.real, r.imag]) and approx(np.r_[rr.real, rr.imag], np.r_[t.real, t.imag])
+
+
+# ------------------------------------------------------------------ polarizing filter (runtests.jl:2469-2535)
+def test_polarization_filter_malus(oracle):
+    thetas = np.arange(1, 360, 10)
+    filt = bmo.PolarizationFilter(5 * mm)
+    R = filt.orientation()
+    ray_dir = R[:, 1].copy()
+    ray_pos = filt.position() - 10 * mm * ray_dir
+    pol_vec = R[:, 0].copy()
+    Rm = bmo.rotation_matrix(ray_dir, math.radians(10))
+    ang_n, ang_a = [], []
+    for th in thetas:
+        beam = bmo.Beam(ray_pos, ray_dir, 1e-6, R[:, 0])
+        oracle.solve_system(bmo.System([filt]), beam)
+        E1 = beam.rays[1].E0
+        assert approx(np.linalg.norm(E1) ** 2, math.cos(math.radians(th - 1)) ** 2, atol=1e-12)  # Malus' law
+        ang_n.append(math.degrees(angle3d(E1.real, pol_vec)))
+        ang_a.append(180.0 if 90 < th - 1 <= 270 else 0.0)
+        bmo.rotate3d(filt, ray_dir, math.radians(10))
+        pol_vec = Rm @ pol_vec
+    assert approx(ang_n, ang_a, atol=1e-5)
+
+
+def test_polarization_filter_tilted(oracle):
+    thetas = np.arange(1, 360, 10)
+    filt = bmo.PolarizationFilter(5 * mm)
+    bmo.translate3d(filt, [0, 10 * mm, 0])
+    bmo.xrotate3d(filt, math.radians(45))
+    bmo.zrotate3d(filt, math.radians(30))
+    R = filt.orientation().copy()
+    ray_dir, local_x = R[:, 1].copy(), R[:, 0].copy()
+    ray_pos = filt.position() - 10 * mm * ray_dir
+    bmo.rotate3d(filt, local_x, math.radians(45))
+    got = []
+    for th in thetas:
+        beam = bmo.Beam(ray_pos, ray_dir, 1e-6, local_x)
+        oracle.solve_system(bmo.System([filt]), beam)
+        got.append(np.linalg.norm(beam.rays[1].E0) ** 2)
+        bmo.rotate3d(filt, ray_dir, math.radians(10))
+    want = np.cos(np.radians(thetas - 1)) ** 2 * 0.75 + 0.25
+    assert approx(got, want)
+
+
+# ------------------------------------------------------------------ Gaussian beamlets (runtests.jl:1811-1932)
+def test_gaussian_parameters_free_space(oracle):  # :1811-1871
+    y = np.arange(-5, 5.0001, 0.01)
+    for lam, w0, M2 in ((500e-9, 1e-3, 1e-3), (1000e-9, 2e-3, 2e-3)):
+        g = bmo.GaussianBeamlet([0.0, 0, 0], [0.0, 1, 0], lam, w0, M2=M2, P0=1, support=[1, 0, 0])
+        zr = math.pi * w0 ** 2 / lam / M2
+        wa = w0 * np.sqrt(1 + (y / zr) ** 2)
+        Ra = y / (y ** 2 + zr ** 2)
+        pa = -np.arctan(y / zr)
+        num = np.array([bmo.beams.gauss_parameters(g, yi) for yi in y])
+        assert np.all(np.abs(wa - num[:, 0]) <= 1e-10)
+        assert np.all(np.abs(Ra - num[:, 1]) <= 5e-9)
+        assert np.all(np.abs(pa - num[:, 2]) <= 1e-7)
+        assert np.all(np.abs(num[:, 3] - w0) <= RTOL * w0)
+
+
+RTOL = math.sqrt(np.finfo(float).eps)
+
+
+def test_gaussian_through_thin_lens_vs_abcd(oracle):  # :1873-1932
+    lam, w0 = 1000e-9, 1e-3
+    zr = math.pi * w0 ** 2 / lam
+    R1 = R2 = 1
+    lens_y, nl = 0.1, 1.5
+    f = 1 / ((nl - 1) * (1 / R1 + 1 / R2))
+    dy = 0.001
+    ys = np.arange(0, 1.5 + 1e-12, dy)
+    w_ana, R_ana = np.zeros(len(ys)), np.zeros(len(ys))
+    q0 = complex(0, zr)
+    for i in range(1, len(ys) + 1):
+        w_ana[i - 1] = math.sqrt(-lam / (math.pi * (1 / q0).imag))
+        R_ana[i - 1] = (1 / q0).real
+        if i * dy == lens_y:
+            q0 = (1 * q0 + 0) / (-1 / f * q0 + 1)
+            continue
+        q0 = (q0 + dy) / 1
+    tl = bmo.ThinLensSDF(R1, R2, 0.025)
+    lens = bmo.Lens(tl, lambda x: nl)
+    bmo.translate3d(lens, [0, lens_y, 0])
+    g = bmo.GaussianBeamlet([0.0, 0, 0], [0.0, 1, 0], lam, w0, support=[1, 0, 0], M2=1)
+    oracle.solve_system(bmo.System([lens]), g)
+    assert len(g.chief.rays) == 3
+    num = np.array([bmo.beams.gauss_parameters(g, yi) for yi in ys])
+    assert np.all(np.abs(w_ana - num[:, 0]) <= 1e-6)
+    ok = np.abs(R_ana - num[:, 1]) <= 1e-2
+    assert ok.sum() / len(ok) > 0.95 and not np.any(np.isnan(num[:, 1]))
+    i = int(np.argmin(w_ana))
+    assert abs(num[0, 2]) <= 1e-3 and abs(num[i, 2]) <= 1e-3
+    assert abs(num[i, 3] - w_ana[i]) <= 1e-7
