@@ -149,6 +149,7 @@ struct StepParams {
     int32_t use_lds;
     Chunk cur, nxt;
     Counters* ctr;
+    unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
     NodeArrays nodes;
     int32_t r_max;
 };
@@ -158,21 +159,80 @@ __device__ inline int prefix_rank(unsigned long long mask) {
     return __popcll(mask & ((1ull << lane_id()) - 1ull));
 }
 
+
+// Block-aggregated slot allocation.  A single address sustains only ~88 returning atomics/us (MI355X_MICROARCH.md
+// "dequeue"): one atomic per wave = 16 K per 1 M-ray launch put a ~0.3 ms floor under every launch.  Here the 4 waves
+// of a block publish their ballot counts in LDS, thread 0 issues ONE atomic per counter, and every wave derives its
+// own offsets.  Block layout in the next chunk: [survivors of wave 0..3][child pairs of wave 0..3].
+struct SlotAlloc {
+    unsigned long long surv_base, child_base, node_base;
+    unsigned long long m_surv, m_split;
+};
+__device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint32_t calls, const StepParams& P, char* scratch) {
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(scratch);                         // [0..3] surv, [4..7] split
+    unsigned long long* w64 = reinterpret_cast<unsigned long long*>(scratch + 32);  // [0] base, [1] nbase
+    SlotAlloc a;
+    a.m_surv = __ballot(survive);
+    a.m_split = __ballot(split);
+    const int wave = (int)(threadIdx.x >> 6);
+    unsigned int c = calls;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane_id() == 0) {
+        w32[wave] = (uint32_t)__popcll(a.m_surv);
+        w32[4 + wave] = (uint32_t)__popcll(a.m_split);
+        w32[8 + wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ts = w32[0] + w32[1] + w32[2] + w32[3], tp = w32[4] + w32[5] + w32[6] + w32[7];
+        const uint32_t tc = w32[8] + w32[9] + w32[10] + w32[11];
+        unsigned long long b = 0, nb = 0;
+        if (ts + tp) b = atomicAdd(&P.ctr->next_count, (unsigned long long)(ts + 2 * tp));
+        if (tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
+        if (tc) atomicAdd(&P.call_shards[(blockIdx.x & 63u) * 16u], (unsigned long long)tc);  // sharded, no return value
+        w64[0] = b;
+        w64[1] = nb;
+    }
+    __syncthreads();
+    uint32_t ps = 0, pp = 0, ts = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) {
+            ps += w32[w];
+            pp += w32[4 + w];
+        }
+        ts += w32[w];
+    }
+    a.surv_base = w64[0] + ps;
+    a.child_base = w64[0] + ts + 2ull * pp;
+    a.node_base = w64[1] + 2ull * pp;
+    return a;
+}
+
 #ifndef BMO_MIN_WAVES
 #define BMO_MIN_WAVES 2  /* <= 256 VGPRs: 2 waves/SIMD measured 1.4x faster than 1; 4 (128 VGPRs) spills */
 #endif
-template <int KIND>
-__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const char* blob = P.blob;
-    if (P.use_lds) {
+// Scene access: the LDS variant derives every table pointer from the __shared__ array so the compiler emits
+// ds_read (a run-time select between an LDS and a global pointer degrades ALL table reads to flat_load: measured
+// 510 flat loads per wave and VALU active only 17 % of wave residency).  The non-LDS variant (scene > 120 KB) reads
+// the blob from global memory / L2.
+template <bool LDS>
+__device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds) {
+    if constexpr (LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(P.blob);
         uint4* dst = reinterpret_cast<uint4*>(lds);
         for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
         __syncthreads();
-        blob = lds;
+        return view_of(lds);
+    } else {
+        return view_of(P.blob);
     }
-    SceneView S = view_of(blob);
+}
+
+template <int KIND, bool LDS>
+__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    SceneView S = stage_scene<LDS>(P, lds);
+    char* scratch = lds + (LDS ? P.blob_bytes : 0u);
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count, cap = P.cur.cap;
@@ -249,18 +309,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
     }
 
     // ---- wave-level compaction: survivors first, then 2 children per splitting lane
-    const unsigned long long m_surv = __ballot(survive);
-    const unsigned long long m_split = __ballot(split);
-    const int n_surv = __popcll(m_surv), n_split = __popcll(m_split);
-    unsigned long long base = 0, nbase = 0;
-    if (n_surv + n_split > 0) {
-        if (lane_id() == 0) {
-            base = atomicAdd(&P.ctr->next_count, (unsigned long long)(n_surv + 2 * n_split));
-            if (n_split) nbase = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * n_split));
-        }
-        base = __shfl(base, 0);
-        nbase = __shfl(nbase, 0);
-    }
+    const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
     const int64_t ncap = P.nxt.cap;
     auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
         if (slot >= ncap) {
@@ -289,14 +338,14 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
         I[I_FLAGS * ncap + slot] = fl;
     };
     if (survive) {
-        const int64_t slot = (int64_t)base + prefix_rank(m_surv);
+        const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
         const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
         write_next(slot, o.next, node, k + 1, o.hint_obj, o.hint_shape, fl, opl_next);
     }
     if (split) {
-        const int r = prefix_rank(m_split);
-        const int64_t slot = (int64_t)base + n_surv + 2 * r;
-        const int64_t cn = (int64_t)nbase + 2 * r;
+        const int r = prefix_rank(al.m_split);
+        const int64_t slot = (int64_t)al.child_base + 2 * r;
+        const int64_t cn = (int64_t)al.node_base + 2 * r;
         if (cn + 1 < P.nodes.cap) {
             const unsigned long long pkey = P.nodes.key[node];
             const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
@@ -318,25 +367,15 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
             atomicAdd(&P.ctr->overflow, 1ull);
         }
     }
-    // ---- reference intersect3d call count (BASELINE metric numerator)
-    unsigned int c = calls;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if (lane_id() == 0 && c) atomicAdd(&P.ctr->calls, (unsigned long long)c);
 }
 
 
 // ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
+template <bool LDS>
 __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const char* blob = P.blob;
-    if (P.use_lds) {
-        const uint4* src = reinterpret_cast<const uint4*>(P.blob);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
-        __syncthreads();
-        blob = lds;
-    }
-    SceneView S = view_of(blob);
+    SceneView S = stage_scene<LDS>(P, lds);
+    char* scratch = lds + (LDS ? P.blob_bytes : 0u);
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count, cap = P.cur.cap;
     const bool valid = j < m;
@@ -405,18 +444,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
             }
         }
     }
-    const unsigned long long m_surv = __ballot(survive);
-    const unsigned long long m_split = __ballot(split);
-    const int n_surv = __popcll(m_surv), n_split = __popcll(m_split);
-    unsigned long long base = 0, nbase = 0;
-    if (n_surv + n_split > 0) {
-        if (lane_id() == 0) {
-            base = atomicAdd(&P.ctr->next_count, (unsigned long long)(n_surv + 2 * n_split));
-            if (n_split) nbase = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * n_split));
-        }
-        base = __shfl(base, 0);
-        nbase = __shfl(nbase, 0);
-    }
+    const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
     const int64_t ncap = P.nxt.cap;
     auto write_next = [&](int64_t slot, const RayS& c, const RayS& w, const RayS& d, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl,
                           double lenA, double lenB, double oplC, double oplW, double oplD) {
@@ -450,14 +478,14 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         I[I_FLAGS * ncap + slot] = fl;
     };
     if (survive) {
-        const int64_t slot = (int64_t)base + prefix_rank(m_surv);
+        const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
         const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
         write_next(slot, o.nc, o.nw, o.nd, node, k + 1, o.hint_obj, o.hint_shape, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
     }
     if (split) {
-        const int r = prefix_rank(m_split);
-        const int64_t slot = (int64_t)base + n_surv + 2 * r;
-        const int64_t cn = (int64_t)nbase + 2 * r;
+        const int r = prefix_rank(al.m_split);
+        const int64_t slot = (int64_t)al.child_base + 2 * r;
+        const int64_t cn = (int64_t)al.node_base + 2 * r;
         if (cn + 1 < P.nodes.cap) {
             const unsigned long long pkey = P.nodes.key[node];
             const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
@@ -484,9 +512,6 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
             atomicAdd(&P.ctr->overflow, 1ull);
         }
     }
-    unsigned int c = calls;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if (lane_id() == 0 && c) atomicAdd(&P.ctr->calls, (unsigned long long)c);
 }
 
 // ------------------------------------------------------------------ small helper kernels
@@ -823,8 +848,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         c.count = used;
     };
 
-    DevBuf ctr_buf;
-    if ((rc = ctr_buf.alloc(sizeof(Counters)))) return rc;
+    DevBuf ctr_buf, shard_buf;
+    if ((rc = ctr_buf.alloc(sizeof(Counters))) || (rc = shard_buf.alloc(64 * 128))) return rc;
+    HIP_TRY(hipMemsetAsync(shard_buf.p, 0, 64 * 128, stream));
     Counters* d_ctr = static_cast<Counters*>(ctr_buf.p);
     Counters h_ctr{0, (unsigned long long)n, 0, 0};
     HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, stream));
@@ -845,13 +871,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipGetLastError());
         DBG("init kernel done");
     }
-    const size_t lds_bytes = use_lds ? blob_bytes : 0;
-    if (lds_bytes > 48 * 1024) {
-        if constexpr (KIND == BMO_BEAM_GAUSSIAN)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_gauss), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        else
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
+    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64;  // + block_alloc scratch
+    void (*kern)(StepParams) = nullptr;
+    if constexpr (KIND == BMO_BEAM_GAUSSIAN) kern = use_lds ? &step_kernel_gauss<true> : &step_kernel_gauss<false>;
+    else kern = use_lds ? &step_kernel<KIND, true> : &step_kernel<KIND, false>;
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
     int64_t n_nodes = n;
     double kernel_ms = 0;
@@ -868,14 +893,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.cur = cur;
         P.nxt = nxt;
         P.ctr = d_ctr;
+        P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
         P.nodes = node_arrays();
         P.r_max = opts->r_max;
         DBG("step %d launching m=%lld", steps, (long long)m);
         HIP_TRY(hipEventRecord(ev_a, stream));
-        if constexpr (KIND == BMO_BEAM_GAUSSIAN)
-            hipLaunchKernelGGL(step_kernel_gauss, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
-        else
-            hipLaunchKernelGGL((step_kernel<KIND>), dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ev_b, stream));
         HIP_TRY(hipMemcpyAsync(&h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -896,7 +919,14 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     lap("steps");
     R->n_nodes = n_nodes;
-    R->calls = h_ctr.calls;
+    {
+        std::vector<unsigned long long> sh(64 * 16);
+        HIP_TRY(hipMemcpyAsync(sh.data(), shard_buf.p, 64 * 128, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long tot = 0;
+        for (int q = 0; q < 64; ++q) tot += sh[(size_t)q * 16];
+        R->calls = tot;
+    }
     R->n_steps = steps;
     R->kernel_ms = kernel_ms;
     int64_t nrec = 0;

@@ -284,6 +284,14 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
     BMO_NOUNROLL
     for (int c = 0; c < nch; ++c) {
         const bmo_shape& ch = uni ? S.shapes[S.children[s.child_begin + c]] : s;
+        if (c > 0 && ch.bs_radius >= 0.0) {
+            // Child skip (result-preserving): outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6.
+            // If p is outside that sphere by more than max(best, 0), the child's value is > best, so it can change neither
+            // the left-fold min (UnionSDF.jl:53-56) nor the first-minimum index (UnionSDF.jl:86-91).
+            const double ox = p.x - ch.bs_center[0], oy = p.y - ch.bs_center[1], oz = p.z - ch.bs_center[2];
+            const double lim = ch.bs_radius + (best > 0.0 ? best : 0.0);
+            if ((ox * ox + oy * oy) + oz * oz > lim * lim) continue;
+        }
         double v = sdf_simple<double>(S, ch, pt);
         if (c == 0) {
             best = v;
@@ -508,6 +516,9 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
         for (int k = 0; k < np; ++k) {
             const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
             const double lim = (o >= 0 && X.shape >= 0) ? X.t + 1e-6 * (1.0 + X.t) : kinf();
+            // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
+            // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
+            if (o >= 0 && sid == hint_shape) continue;
             Hit tmp = intersect_shape(S, sid, pos, dir, lim);
             if (tmp.shape < 0) continue;
             if (res.shape < 0) {
