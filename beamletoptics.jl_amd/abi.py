@@ -40,8 +40,9 @@ class SceneDesc(C.Structure):
         ("n_tris", C.c_int32), ("n_media", C.c_int32), ("n_lambda", C.c_int32), ("n_detectors", C.c_int32),
         ("objects", C.POINTER(Object)), ("shapes", C.POINTER(Shape)), ("children", C.POINTER(C.c_int32)),
         ("tris", C.POINTER(C.c_double)), ("n_table", C.POINTER(C.c_double)), ("lambdas", C.POINTER(C.c_double)),
+        ("coefs", C.POINTER(C.c_double)),
         ("eps_srf", C.c_double), ("eps_ray", C.c_double), ("eps_ins", C.c_double), ("mt_keps", C.c_double),
-        ("mt_leps", C.c_double), ("grad_h", C.c_double), ("march_iters", C.c_int32), ("reserved", C.c_int32),
+        ("mt_leps", C.c_double), ("grad_h", C.c_double), ("march_iters", C.c_int32), ("n_coefs", C.c_int32),
     ]
 
 

@@ -211,8 +211,9 @@ class Lens(AbstractObject):
         elif len(args) == 4:
             shape = sh.lens_shape_from_surfaces(args[0], args[1], args[2])
             n = args[3]
-        elif len(args) == 3:  # Lens(front_surface, center_thickness, n) :293-302
-            shape = sh.lens_shape_from_surfaces(args[0], sh.CircularFlatSurface(args[0].diameter), args[1])
+        elif len(args) == 3:  # Lens(front_surface, center_thickness, n) :293-302 / :390-399
+            flat = sh.RectangularFlatSurface if isinstance(args[0], sh.CylindricalSurface) else sh.CircularFlatSurface
+            shape = sh.lens_shape_from_surfaces(args[0], flat(args[0].diameter), args[1])
             n = args[2]
         else:
             raise TypeError("Lens(shape, n) or Lens(front, back, thickness, n)")

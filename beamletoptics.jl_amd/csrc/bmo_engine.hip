@@ -67,7 +67,8 @@ struct BlobHeader {
     int32_t n_objects, n_shapes, n_children, n_tris, n_media, n_lambda, n_detectors, march_iters;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
-    uint32_t has_splitter, pad;
+    uint32_t has_splitter, off_coefs;
+    uint32_t has_asphere, pad;
 };
 
 __host__ __device__ inline SceneView view_of(const char* blob) {
@@ -78,6 +79,7 @@ __host__ __device__ inline SceneView view_of(const char* blob) {
     S.children = reinterpret_cast<const int32_t*>(blob + h->off_children);
     S.tris = reinterpret_cast<const double*>(blob + h->off_tris);
     S.n_table = reinterpret_cast<const double*>(blob + h->off_ntable);
+    S.coefs = reinterpret_cast<const double*>(blob + h->off_coefs);
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -228,7 +230,7 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
     }
 }
 
-template <int KIND, bool LDS>
+template <int KIND, bool LDS, bool ASPH>
 __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
         if (flags & F_DEAD) {
             status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
         } else {
-            X = tracing_step(S, ray.pos, ray.dir, I[I_HOBJ * cap + j], I[I_HSHAPE * cap + j], calls);
+            X = tracing_step<ASPH>(S, ray.pos, ray.dir, I[I_HOBJ * cap + j], I[I_HSHAPE * cap + j], calls);
             if (X.shape < 0) {
                 status = BMO_NODE_MISS;
             } else {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
 
 
 // ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
-template <bool LDS>
+template <bool LDS, bool ASPH>
 __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         if (flags & F_DEAD) {
             status = BMO_NODE_RMAX;
         } else {
-            gauss_step(S, g, o, calls);
+            gauss_step<ASPH>(S, g, o, calls);
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
             else if (o.outcome == OUT_SPLIT) {
@@ -873,8 +875,14 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64;  // + block_alloc scratch
     void (*kern)(StepParams) = nullptr;
-    if constexpr (KIND == BMO_BEAM_GAUSSIAN) kern = use_lds ? &step_kernel_gauss<true> : &step_kernel_gauss<false>;
-    else kern = use_lds ? &step_kernel<KIND, true> : &step_kernel<KIND, false>;
+    const bool asph = scene->hdr.has_asphere != 0;
+    if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
+        kern = use_lds ? (asph ? &step_kernel_gauss<true, true> : &step_kernel_gauss<true, false>)
+                       : (asph ? &step_kernel_gauss<false, true> : &step_kernel_gauss<false, false>);
+    } else {
+        kern = use_lds ? (asph ? &step_kernel<KIND, true, true> : &step_kernel<KIND, true, false>)
+                       : (asph ? &step_kernel<KIND, false, true> : &step_kernel<KIND, false, false>);
+    }
     if (lds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
@@ -1036,10 +1044,15 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
                 if (s.kind == BMO_SHAPE_MENISCUS && ck == BMO_SHAPE_MENISCUS) return fail(BMO_ERR_INVALID, "nested meniscus");
             }
         }
+        if ((s.kind == BMO_SHAPE_ASPH_CONVEX || s.kind == BMO_SHAPE_ASPH_CONCAVE) &&
+            (s.child_begin < 0 || s.child_count < 0 || s.child_begin + s.child_count > d->n_coefs))
+            return fail(BMO_ERR_INVALID, "aspheric coefficient range out of bounds");
         if (s.kind == BMO_SHAPE_MESH && (s.tri_begin < 0 || s.tri_begin + s.tri_count > d->n_tris))
             return fail(BMO_ERR_INVALID, "triangle range out of bounds");
     }
-    bool has_split = false;
+    bool has_split = false, has_asph = false;
+    for (int i = 0; i < d->n_shapes; ++i)
+        if (d->shapes[i].kind >= BMO_SHAPE_ASPH_CONVEX && d->shapes[i].kind <= BMO_SHAPE_CYL_CONCAVE) has_asph = true;  // extended shapes
     for (int i = 0; i < d->n_objects; ++i) {
         const bmo_object& o = d->objects[i];
         if (o.kind < 0 || o.kind >= BMO_OBJ_KIND_COUNT) return fail(BMO_ERR_UNSUPPORTED, "unknown object kind");
@@ -1073,6 +1086,7 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     h.mt_leps = d->mt_leps;
     h.grad_h = d->grad_h;
     h.has_splitter = has_split ? 1 : 0;
+    h.has_asphere = has_asph ? 1 : 0;
     size_t off = al(sizeof(BlobHeader));
     h.off_objects = (uint32_t)off;
     off = al(off + sizeof(bmo_object) * (size_t)d->n_objects);
@@ -1084,6 +1098,8 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     off = al(off + 72 * (size_t)d->n_tris);
     h.off_ntable = (uint32_t)off;
     off = al(off + 8 * (size_t)std::max(1, d->n_media) * (size_t)d->n_lambda);
+    h.off_coefs = (uint32_t)off;
+    off = al(off + 8 * (size_t)std::max(1, d->n_coefs));
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -1092,6 +1108,7 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_children) std::memcpy(sc->blob.data() + h.off_children, d->children, 4 * (size_t)d->n_children);
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
+    if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
     sc->hdr = h;
     *out = sc.release();
     return BMO_OK;

@@ -47,6 +47,7 @@ struct SceneView {
     const int32_t* children;
     const double* tris;
     const double* n_table;
+    const double* coefs;
     int32_t n_objects, n_lambda;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int32_t march_iters;
@@ -182,9 +183,120 @@ BMO_HD T slab2(const T& dx, const T& dy) {
     return jmin(mx, 0.0) + norm2(ax, ay);
 }
 
+
+// ------------------------------------------------------------------ aspheres (AsphericalLensSDF.jl:133-307)
+BMO_HD double ipow(double x, int n) {  // Base.power_by_squaring (small exponents multiply out like literal_pow)
+    if (n == 0) return 1.0;
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return x * x * x;
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= x;
+        x *= x;
+        n >>= 1;
+    }
+    return r;
+}
+BMO_HD double knan() { return kinf() - kinf(); }
+BMO_HD double jsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+// aspheric_equation :133-141 and the first component of gradient_aspheric_equation :147-156, one pass over the coefficients
+BMO_HD void asph_eval(double r, double c, double k, const double* a, int na, double& z, double& g) {
+    const double r2 = r * r;
+    const double sa1 = 1 - (1 + k) * (c * c) * r2;
+    const double Ri = 1 / c;
+    const double sa2 = 1 - (r * r) * (1 + k) / (Ri * Ri);
+    double sum_a = 0.0, sum_r = 0.0;
+    BMO_NOUNROLL
+    for (int i = 1; i <= na; ++i) {
+        const double ta = a[i - 1] * ipow(r2, i);
+        const double tr = 2 * i * a[i - 1] * ipow(r, 2 * (i - 1) + 1);
+        sum_a = i == 1 ? ta : sum_a + ta;
+        sum_r = i == 1 ? tr : sum_r + tr;
+    }
+    z = sa1 < 0 ? knan() : c * r2 / (1 + sqrt(sa1)) + sum_a;
+    if (sa2 < 0) {
+        g = knan();
+    } else {
+        const double sq = sqrt(sa2);
+        const double gr = 2 * r / (Ri * (sq + 1)) + (r * r * r) * (1 + k) / ((Ri * Ri * Ri) * sq * ((sq + 1) * (sq + 1)));
+        g = -sum_r - gr;
+    }
+}
+BMO_HD double norm_g(double g1) { return sqrt(g1 * g1 + 1.0 * 1.0); }
+BMO_HD double sd_line_segment(double px, double py, double ax, double ay, double bx, double by) {  // :164-169
+    const double pax = px - ax, pay = py - ay, bax = bx - ax, bay = by - ay;
+    double h = (pax * bax + pay * bay) / (bax * bax + bay * bay);
+    h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
+    const double ex = pax - h * bax, ey = pay - h * bay;
+    return sqrt(ex * ex + ey * ey);
+}
+// convex_/concave_aspheric_surface_distance :186-307
+BMO_HD double asph_distance(bool convex, double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
+    const double r2 = r * r, r2_bound = (d / 2) * (d / 2);
+    double zv, g, zb, gb;
+    asph_eval(r, c, k, a, na, zv, g);
+    asph_eval(d / 2, c, k, a, na, zb, gb);
+    const double e = r - jsign(r) * d / 2;
+    if (convex) {
+        if (isnan_(zv) || isnan_(g) || r2 > r2_bound) {
+            double db;
+            if (z < zb) db = sqrt(e * e + (z - zb) * (z - zb));
+            else if (zb < z && z < 0) db = sqrt(e * e);
+            else if (z > 0 && (jsign(c) == 1 && zb < 0)) db = sqrt(e * e + z * z);
+            else db = sqrt(e * e + (z - zb) * (z - zb));
+            return db / norm_g(gb);
+        }
+        const double da = fabs(z - zv) / norm_g(g);
+        if (jsign(c) == 1 && zb < 0) {
+            const double n = norm_g(gb);
+            const double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, max_sag) / n;
+            const double s2 = sd_line_segment(r, z, d / 2, max_sag, -d / 2, max_sag) / n;
+            const double s3 = sd_line_segment(r, z, -d / 2, max_sag, -d / 2, zb) / n;
+            const double m = jmin(jmin(jmin(da, s1), s2), s3);
+            return (zv < z && z < max_sag) ? -m : m;
+        }
+        const double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+        if (jsign(c) * zv < jsign(c) * z && jsign(c) * z < jsign(c) * zb) return -jmin(sdl, da);
+        return jmin(sdl, da);
+    }
+    if (isnan_(zv) || isnan_(g)) {
+        double db;
+        if (z < 0) db = sqrt(e * e + z * z);
+        else if (0 < z && z < zb) db = sqrt(e * e);
+        else db = sqrt(e * e + (z - zb) * (z - zb));
+        return db / norm_g(gb);
+    }
+    const double da = fabs(z - zv) / norm_g(g);
+    if (max_sag > 0 && zb < 0) {
+        const double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+        if (r2 > r2_bound) return sdl;
+        if (zb < z && z < zv) return -jmin(da, sdl);
+        if (zb > 0 && (0.0 < z && z < zv)) return -jmin(da, sdl);
+        return jmin(da, sdl);
+    }
+    const double n = norm_g(gb);
+    const double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, 0.0) / n;
+    const double s2 = sd_line_segment(r, z, d / 2, 0.0, -d / 2, 0.0) / n;
+    const double s3 = sd_line_segment(r, z, -d / 2, 0.0, -d / 2, zb) / n;
+    if (r2 > r2_bound) return jmin(jmin(s1, s2), s3);
+    const double m = jmin(jmin(jmin(da, s1), s2), s3);
+    if (zb < 0 && (zv < z && z < 0.0)) return -m;
+    if (zb > 0 && (0.0 < z && z < zv)) return -m;
+    return m;
+}
+// aspheres are never differentiated (normal3d = numeric_gradient, AsphericalLensSDF.jl:5): the Dual overload returns NaN,
+// which sends normal_any straight to the same central-difference stencil.
+BMO_HD double asph_leaf(const bmo_shape& s, const double* coefs, double r, double y) {
+    return asph_distance(s.kind == BMO_SHAPE_ASPH_CONVEX, r, y, 1 / s.p[0], s.p[1], s.p[2], coefs + s.child_begin, s.child_count, s.p[3]);
+}
+BMO_HD Dual asph_leaf(const bmo_shape&, const double*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
+
 // leaf SDFs; `pt` is in the parent's frame (world, or the meniscus frame)
-template <class T>
-BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt) {
+// ASPH ("extended shapes"): compile the aspheric and cylinder-lens branches in.  Scenes without them run kernels
+// instantiated with ASPH = false (half the code, fewer registers).
+template <class T, bool ASPH>
+BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt, const double* coefs) {
     v3<T> p = to_local(s, pt);
     const int kind = s.kind;
     if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
@@ -250,11 +362,42 @@ BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt) {
         T pln = (p.x + p.y) / 1.4142135623730951;  // sqrt(2)
         return jmax(box, pln);
     }
+    if constexpr (ASPH) {
+        if (kind == BMO_SHAPE_ASPH_CONVEX || kind == BMO_SHAPE_ASPH_CONCAVE) {  // AsphericalLensSDF.jl:309-349 (op_revolve_z)
+            T r = norm2(p.x, p.z) - 0.0;
+            return asph_leaf(s, coefs, r, p.y);
+        }
+    }
+    if constexpr (ASPH) {
+        if (kind == BMO_SHAPE_CYL_CONVEX) {  // CylindricalSDF.jl:62-85: op_extrude_x of sdf_cut_disk
+            const double r = s.p[0], dia = s.p[1], height = s.p[2];
+            const double h = sqrt(r * r - (dia / 2) * (dia / 2));
+            const double w = sqrt(r * r - h * h);
+            T q1 = jabs(p.y), q2 = p.z;
+            const double a = val(q1), b = val(q2);
+            const double sv = jmax((h - r) * (a * a) + (w * w) * (h + r - 2 * b), h * a - w * b);
+            T d2 = (sv < 0) ? norm2(q1, q2) - r : ((a < w) ? h - q2 : norm2(q1 - w, q2 - h));
+            T w2 = jabs(p.x) - height / 2;
+            return jmin(jmax(d2, w2), 0.0) + norm2(jmax(d2, 0.0), jmax(w2, 0.0));
+        }
+        if (kind == BMO_SHAPE_CYL_CONCAVE) {  // CylindricalSDF.jl:123-139
+            const double radius = s.p[0], dia = s.p[1], height = s.p[2];
+            const double ar = fabs(radius);
+            const double sg = ar - sqrt(ar * ar - 0.25 * (dia * dia));
+            T x0 = p.x + 0.0, z0 = p.z + 0.0;
+            T y1 = p.y + (-radius);
+            T c = slab2(jabs(norm2(p.z, y1)) - ar, jabs(x0) - height / 2);
+            T y2 = p.y + (-sg / 2 * jsign(radius));
+            T qx = jabs(x0) - height / 2, qy = jabs(y2) - sg / 2, qz = jabs(z0) - dia / 2;
+            T l = norm3t(jmax(qx, 0.0), jmax(qy, 0.0), jmax(qz, 0.0)) + jmin(jmax(qx, jmax(qy, qz)), 0.0);
+            return jmax(l, -c);
+        }
+    }
     return T{} + kinf();
 }
 
 // leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
-template <class T>
+template <class T, bool ASPH>
 BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
     const bool men = s.kind == BMO_SHAPE_MENISCUS;
     v3<T> p = pt;
@@ -264,7 +407,7 @@ BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
         const bmo_shape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
-        T v = sdf_leaf<T>(leaf, p);
+        T v = sdf_leaf<T, ASPH>(leaf, p, S.coefs);
         if (q == 0) a = v;
         else if (q == 1) b = v;
         else c = v;
@@ -275,6 +418,7 @@ BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
 
 // sdf(shape, p) for any SDF shape incl. UnionSDF (UnionSDF.jl:53-56, left-fold min) together with
 // the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
+template <bool ASPH>
 BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t& best_child) {
     const v3<double> pt{p.x, p.y, p.z};
     const bool uni = s.kind == BMO_SHAPE_UNION;
@@ -284,7 +428,7 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
     BMO_NOUNROLL
     for (int c = 0; c < nch; ++c) {
         const bmo_shape& ch = uni ? S.shapes[S.children[s.child_begin + c]] : s;
-        if (c > 0 && ch.bs_radius >= 0.0) {
+        if (c > 0 && ch.bs_radius >= 0.0 && !(ch.flags & BMO_SHAPE_FLAG_INEXACT)) {
             // Child skip (result-preserving): outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6.
             // If p is outside that sphere by more than max(best, 0), the child's value is > best, so it can change neither
             // the left-fold min (UnionSDF.jl:53-56) nor the first-minimum index (UnionSDF.jl:86-91).
@@ -292,7 +436,7 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
             const double lim = ch.bs_radius + (best > 0.0 ? best : 0.0);
             if ((ox * ox + oy * oy) + oz * oz > lim * lim) continue;
         }
-        double v = sdf_simple<double>(S, ch, pt);
+        double v = sdf_simple<double, ASPH>(S, ch, pt);
         if (c == 0) {
             best = v;
         } else {
@@ -305,10 +449,11 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
 
 // normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88)
+template <bool ASPH>
 BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t best_child) {
     const bmo_shape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
     v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
-    Dual y = sdf_simple<Dual>(S, sh, x);
+    Dual y = sdf_simple<Dual, ASPH>(S, sh, x);
     d3 n = normalize_inv(d3{y.a, y.b, y.c});
     if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
     const double e = S.grad_h;
@@ -319,7 +464,7 @@ BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_
         const bool minus = q & 1;
         double ox = ax == 0 ? e : 0.0, oy = ax == 1 ? e : 0.0, oz = ax == 2 ? e : 0.0;
         v3<double> pt = minus ? v3<double>{p.x - ox, p.y - oy, p.z - oz} : v3<double>{p.x + ox, p.y + oy, p.z + oz};
-        double v = sdf_simple<double>(S, sh, pt);
+        double v = sdf_simple<double, ASPH>(S, sh, pt);
         double contrib = minus ? -v : v;
         // f(p+h) - f(p-h): the '+' value is stored first, the '-' value subtracted from it
         if (ax == 0) g0 = minus ? g0 - v : v;
@@ -384,6 +529,7 @@ BMO_HD double moeller_trumbore(const double* f, const d3& pos, const d3& dir, do
 //   outside march stops once its running t0 exceeds it.  t0 only grows by positive steps until the final
 //   sub-tolerance step (>= -1e-8*dist for these 1-Lipschitz SDFs), so with the caller's 1e-6 margin the
 //   pruned shape is provably a loser; results are unchanged (DESIGN.md "nearest-hit prune").
+template <bool ASPH>
 BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit) {
     const bmo_shape& s = S.shapes[sid];
     Hit h = no_hit();
@@ -413,6 +559,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         return h;
     }
     enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2 };
+    const bool exact = !(s.flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
     int phase = CLASSIFY;
     d3 pos = pos0, dir = dir0;
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
@@ -426,7 +573,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
             pos = axpy3(pos, dist, dir);
         }
         int32_t bc;
-        const double d = sdf_any(S, s, pos, bc);
+        const double d = sdf_any<ASPH>(S, s, pos, bc);
         bool want_normal = false;
         if (phase == CLASSIFY) {
             if (d > S.eps_srf) {
@@ -435,7 +582,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
                 t0 = d;
                 i_out = 1;
                 if (!(i_out <= S.march_iters)) return h;
-                if (t0 > t_limit) return h;
+                if (exact && t0 > t_limit) return h;
                 continue;
             }
             want_normal = true;
@@ -460,14 +607,14 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
             if (d < S.eps_ray) want_normal = true;
             else {
                 if (cull_receding(s, pos, dir)) return h;  // provable miss: skip the rest of the 1000 evaluations
-                if (!back && t0 > t_limit) return h;        // provable loser of the nearest-hit selection
+                if (exact && !back && t0 > t_limit) return h;  // provable loser of the nearest-hit selection
                 if (!(i_out <= S.march_iters)) return h;
                 continue;
             }
         }
         // single normal evaluation site (classification on the surface, or hit)
         (void)want_normal;
-        const d3 n = normal_any(S, s, pos, bc);
+        const d3 n = normal_any<ASPH>(S, s, pos, bc);
         if (phase == CLASSIFY) {
             if (dot3(dir, n) <= 0) {
                 phase = INSIDE;
@@ -489,6 +636,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
 // one loop over "slots": slot -1 is the hinted SHAPE (if any), slots 0..M-1 are the leaf objects.
 // Object-level rules: SingleShape/MultiShape AbstractRay.jl:118-155, plate splitter
 // PlateBeamsplitter.jl:160-187, NonInteractable.jl:19.  `calls` counts the reference's intersect3d calls.
+template <bool ASPH>
 BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls) {
     Hit X = no_hit();
     const int first = hint_shape >= 0 ? -1 : 0;
@@ -519,7 +667,7 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
             // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
             // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
             if (o >= 0 && sid == hint_shape) continue;
-            Hit tmp = intersect_shape(S, sid, pos, dir, lim);
+            Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim);
             if (tmp.shape < 0) continue;
             if (res.shape < 0) {
                 res = tmp;
@@ -993,6 +1141,27 @@ BMO_HD double gauss_w0_at(const GaussIn& g, double t_total, double temp) {
     return w0;
 }
 
+
+// by-value selection of one of three rays / hits with scalar selects (a reference select `r == 0 ? g.c : ...` forces the
+// structs into scratch memory: the first Gaussian kernel spilled 1.8 KB per lane)
+BMO_HD double sel3(int r, double a, double b, double c) { return r == 0 ? a : (r == 1 ? b : c); }
+BMO_HD RayS pick_ray(int r, const RayS& a, const RayS& b, const RayS& c) {
+    RayS o;
+    o.pos = {sel3(r, a.pos.x, b.pos.x, c.pos.x), sel3(r, a.pos.y, b.pos.y, c.pos.y), sel3(r, a.pos.z, b.pos.z, c.pos.z)};
+    o.dir = {sel3(r, a.dir.x, b.dir.x, c.dir.x), sel3(r, a.dir.y, b.dir.y, c.dir.y), sel3(r, a.dir.z, b.dir.z, c.dir.z)};
+    o.n = sel3(r, a.n, b.n, c.n);
+    return o;
+}
+BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
+    Hit o;
+    o.t = sel3(r, a.t, b.t, c.t);
+    o.n = {sel3(r, a.n.x, b.n.x, c.n.x), sel3(r, a.n.y, b.n.y, c.n.y), sel3(r, a.n.z, b.n.z, c.n.z)};
+    o.obj = r == 0 ? a.obj : (r == 1 ? b.obj : c.obj);
+    o.shape = r == 0 ? a.shape : (r == 1 ? b.shape : c.shape);
+    return o;
+}
+
+template <bool ASPH>
 BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls) {
     o.outcome = OUT_MISS;
     o.status = 0;
@@ -1004,8 +1173,8 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
     bool all_hit = true;
     BMO_NOUNROLL
     for (int r = 0; r < 3; ++r) {
-        const RayS& ray = r == 0 ? g.c : (r == 1 ? g.w : g.d);
-        Hit X = tracing_step(S, ray.pos, ray.dir, g.hint_obj, g.hint_shape, calls);
+        const RayS ray = pick_ray(r, g.c, g.w, g.d);
+        Hit X = tracing_step<ASPH>(S, ray.pos, ray.dir, g.hint_obj, g.hint_shape, calls);
         if (r == 0) o.Xc = X;
         else if (r == 1) o.Xw = X;
         else o.Xd = X;
@@ -1031,8 +1200,8 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
     bool all_continue = true;
     BMO_NOUNROLL
     for (int r = 0; r < 3; ++r) {
-        const RayS& ray = r == 0 ? g.c : (r == 1 ? g.w : g.d);
-        Hit X = r == 0 ? o.Xc : (r == 1 ? o.Xw : o.Xd);
+        const RayS ray = pick_ray(r, g.c, g.w, g.d);
+        Hit X = pick_hit(r, o.Xc, o.Xw, o.Xd);
         X.obj = oid;
         const double opl = r == 0 ? g.oplC : (r == 1 ? g.oplW : g.oplD);
         StepOut so;

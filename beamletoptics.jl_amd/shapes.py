@@ -14,7 +14,9 @@ import numpy as np
 from . import linalg as la
 
 # shape kinds (include/bmo.h enum bmo_shape_kind)
-K_MESH, K_SPHERE, K_PLANO, K_CONVEX, K_CONCAVE, K_UNION, K_BOX, K_CYLINDER, K_CUTSPHERE, K_RING, K_PRISM, K_MENISCUS, K_POINT = range(13)
+(K_MESH, K_SPHERE, K_PLANO, K_CONVEX, K_CONCAVE, K_UNION, K_BOX, K_CYLINDER, K_CUTSPHERE, K_RING, K_PRISM, K_MENISCUS, K_POINT, K_ASPH_CONVEX,
+ K_ASPH_CONCAVE, K_CYL_CONVEX, K_CYL_CONCAVE) = range(17)
+FLAG_INEXACT = 1
 
 
 class AbstractShape:
@@ -332,6 +334,197 @@ class TestPointSDF(AbstractSDF):  # test/runtests.jl:926-947 (KAT fixture)
         return [0, 0, 0], 0.0
 
 
+# ------------------------------------------------------------------- aspheres (AsphericalLensSDF.jl)
+def _ipow(x, n):
+    if n == 0:
+        return 1.0
+    if n <= 3:
+        r = x
+        for _ in range(n - 1):
+            r = r * x
+        return r
+    r = 1.0
+    while n > 0:
+        if n & 1:
+            r *= x
+        x *= x
+        n >>= 1
+    return r
+
+
+def aspheric_equation(r, c, k, coeffs):
+    """AsphericalLensSDF.jl:133-141"""
+    r2 = r * r
+    sqrt_arg = 1 - (1 + k) * (c * c) * r2
+    if sqrt_arg < 0:
+        return math.nan
+    sum_a = 0.0
+    for i, a in enumerate(coeffs, start=1):
+        term = a * _ipow(r2, i)
+        sum_a = term if i == 1 else sum_a + term
+    return c * r2 / (1 + math.sqrt(sqrt_arg)) + sum_a
+
+
+def gradient_aspheric_equation(r, c, k, coeffs):
+    """AsphericalLensSDF.jl:147-156 (first component; the second is 1)."""
+    Ri = 1 / c
+    sqrt_arg = 1 - (r * r) * (1 + k) / (Ri * Ri)
+    if sqrt_arg < 0:
+        return math.nan
+    sq = math.sqrt(sqrt_arg)
+    gr = 2 * r / (Ri * (sq + 1)) + (r * r * r) * (1 + k) / ((Ri * Ri * Ri) * sq * ((sq + 1) * (sq + 1)))
+    sum_r = 0.0
+    for m, a in enumerate(coeffs, start=1):
+        term = 2 * m * a * _ipow(r, 2 * (m - 1) + 1)
+        sum_r = term if m == 1 else sum_r + term
+    return -sum_r - gr
+
+
+def _find_zero_bisection(f, a, b, tol=1e-10, max_iter=1000):
+    """Utils/MiscUtils.jl:87-108"""
+    fa, fb = f(a), f(b)
+    if _sign(fa) == _sign(fb):
+        raise ValueError("Bisection requires a sign change")
+    for _ in range(max_iter):
+        mid = (a + b) / 2
+        fmid = f(mid)
+        if abs(fmid) < tol:
+            return mid
+        if _sign(fa) == _sign(fmid):
+            a, fa = mid, fmid
+        else:
+            b, fb = mid, fmid
+    raise ValueError("Bisection did not converge")
+
+
+def max_aspheric_value(c, k, coeffs, d):
+    """AsphericalLensSDF.jl:53-67"""
+    f = lambda r: aspheric_equation(r, c, k, coeffs)
+    fp = lambda r: gradient_aspheric_equation(r, c, k, coeffs)
+    a, b = 1e-8, d / 2
+    if _sign(fp(a)) == _sign(fp(b)):
+        r_max = a if abs(f(a)) > abs(f(b)) else b
+    else:
+        r_max = _find_zero_bisection(fp, a, b)
+    return f(r_max), r_max
+
+
+class _AsphericalSurfaceSDF(AbstractSDF):
+    flags = FLAG_INEXACT  # first-order distance estimate: bounding-sphere culls only
+
+    def __init__(self, coefficients, radius, conic_constant, diameter):
+        super().__init__()
+        self.coefficients = [float(x) for x in coefficients]
+        self.radius = float(radius)
+        self.conic_constant = float(conic_constant)
+        self.diameter = float(diameter)
+        self.max_sag = max_aspheric_value(1 / self.radius, self.conic_constant, self.coefficients, self.diameter)
+
+    def edge_sag_value(self):
+        return aspheric_equation(self.diameter / 2, 1 / self.radius, self.conic_constant, self.coefficients)
+
+    def params(self):
+        return [self.radius, self.conic_constant, self.diameter, self.max_sag[0]]
+
+    def _local_bound(self):
+        # the closed 2D perimeter lives in |r| <= d/2, z between 0, the edge sag and the extreme sag
+        zs = [0.0, self.edge_sag_value(), self.max_sag[0]]
+        lo, hi = min(zs), max(zs)
+        return [0, (lo + hi) / 2, 0], math.hypot((hi - lo) / 2, self.diameter / 2)
+
+
+class ConvexAsphericalSurfaceSDF(_AsphericalSurfaceSDF):  # AsphericalLensSDF.jl:19-48
+    kind = K_ASPH_CONVEX
+
+    @property
+    def thickness(self):
+        sag = self.edge_sag_value()
+        return self.max_sag[0] if (self.max_sag[0] > 0 and sag < 0) else abs(sag)
+
+
+class ConcaveAsphericalSurfaceSDF(_AsphericalSurfaceSDF):  # AsphericalLensSDF.jl:85-121
+    kind = K_ASPH_CONCAVE
+
+    def __init__(self, coefficients, radius, conic_constant, diameter, mechanical_diameter=None):
+        super().__init__(coefficients, radius, conic_constant, diameter)
+        self.mechanical_diameter = float(diameter if mechanical_diameter is None else mechanical_diameter)
+
+    @property
+    def thickness(self):
+        sag = self.edge_sag_value()
+        return abs(sag) if (self.max_sag[0] > 0 and sag < 0) else 0.0
+
+
+class EvenAsphericalSurface:  # AsphericalLensSDF.jl:426-497
+    def __init__(self, radius, diameter, conic_constant, coefficients, mechanical_diameter=None):
+        self.radius = float(radius)
+        self.diameter = float(diameter)
+        self.mechanical_diameter = float(diameter if mechanical_diameter is None else mechanical_diameter)
+        self.conic_constant = float(conic_constant)
+        self.coefficients = [float(x) for x in coefficients]
+
+
+def PlanoConvexAsphericalLensSDF(r, l, d, k, coeffs):  # AsphericalLensSDF.jl:364-376
+    s = aspheric_equation(d / 2, 1 / r, k, coeffs)
+    front = ConvexAsphericalSurfaceSDF(coeffs, r, k, d)
+    back = CylinderSDF(d / 2, (l - abs(s)) / 2)
+    translate3d(front, [0, -_sign(r) * (l / 2 + abs(s) / 2), 0])
+    return front + back
+
+
+# ------------------------------------------------------------------- cylinder lenses (CylindricalSDF.jl)
+class ConvexCylinderSDF(AbstractSDF):  # CylindricalSDF.jl:25-60
+    kind = K_CYL_CONVEX
+
+    def __init__(self, radius, diameter, height):
+        super().__init__()
+        self.radius, self.diameter, self.height = float(radius), float(diameter), float(height)
+        xrotate3d(self, math.pi / 2)
+        translate3d(self, [0, radius, 0])
+
+    @property
+    def thickness(self):
+        return abs(la.sag(self.radius, self.diameter))
+
+    def params(self):
+        return [self.radius, self.diameter, self.height]
+
+    def _local_bound(self):
+        # local frame: extrusion along x (|x| <= h/2), cut disk of radius r in (y, z) with z >= sqrt(r^2 - (d/2)^2)
+        hc = math.sqrt(self.radius ** 2 - (self.diameter / 2) ** 2)
+        zc = (hc + self.radius) / 2
+        return [0, 0, zc], math.sqrt((self.height / 2) ** 2 + (self.diameter / 2) ** 2 + ((self.radius - hc) / 2) ** 2)
+
+
+class ConcaveCylinderSDF(AbstractSDF):  # CylindricalSDF.jl:92-139
+    kind = K_CYL_CONCAVE
+    thickness = 0.0
+
+    def __init__(self, radius, diameter, height):
+        super().__init__()
+        self.radius, self.diameter, self.height = float(radius), float(diameter), float(height)
+
+    def params(self):
+        return [self.radius, self.diameter, self.height]
+
+    def _local_bound(self):
+        sg = la.sag(abs(self.radius), self.diameter)
+        yc = sg / 2 * _sign(self.radius)
+        return [0, yc, 0], math.sqrt((self.height / 2) ** 2 + (sg / 2) ** 2 + (self.diameter / 2) ** 2)
+
+
+class CylindricalSurface:  # CylindricalSDF.jl:160-215
+    def __init__(self, radius, diameter, height, mechanical_diameter=None):
+        self.radius, self.diameter, self.height = float(radius), float(diameter), float(height)
+        self.mechanical_diameter = float(diameter if mechanical_diameter is None else mechanical_diameter)
+
+
+class RectangularFlatSurface:  # CylindricalSDF.jl:224-229
+    def __init__(self, size):
+        self.size = self.diameter = self.mechanical_diameter = float(size)
+        self.radius = math.inf
+
+
 def _enclose(spheres):
     """Conservative sphere around a list of (centre, radius)."""
     c, r = np.array(spheres[0][0], dtype=np.float64), float(spheres[0][1])
@@ -533,8 +726,21 @@ class SphericalSurface:  # SphericalLensSDF.jl:397-454
 
 def _surface_sdf(s, orient):
     """sdf(surface, orientation) SphericalLensSDF.jl:423-454 / AbstractSurface.jl:104."""
-    if isinstance(s, CircularFlatSurface) or math.isinf(s.radius):
+    if isinstance(s, (CircularFlatSurface, RectangularFlatSurface)) or math.isinf(s.radius):
         return None
+    if isinstance(s, EvenAsphericalSurface):  # AsphericalLensSDF.jl:473-497 (no pi rotation: the sign of r carries it)
+        args = (s.coefficients, s.radius, s.conic_constant, s.diameter)
+        if orient == "forward":
+            return ConvexAsphericalSurfaceSDF(*args) if s.radius > 0 else ConcaveAsphericalSurfaceSDF(*args)
+        if orient == "backward":
+            return ConcaveAsphericalSurfaceSDF(*args) if s.radius > 0 else ConvexAsphericalSurfaceSDF(*args)
+        raise ValueError("aspheric meniscus lenses are not supported by the reference either")
+    if isinstance(s, CylindricalSurface):  # CylindricalSDF.jl:187-215
+        if orient == "forward":
+            return ConvexCylinderSDF(s.radius, s.diameter, s.height) if s.radius > 0 else ConcaveCylinderSDF(s.radius, s.diameter, s.height)
+        if orient == "backward":
+            return ConcaveCylinderSDF(s.radius, s.diameter, s.height) if s.radius > 0 else ConvexCylinderSDF(-s.radius, s.diameter, s.height)
+        raise ValueError(orient)
     if orient == "forward":
         return ConvexSphericalSurfaceSDF(s.radius, s.diameter) if s.radius > 0 else ConcaveSphericalSurfaceSDF(abs(s.radius), s.diameter)
     if orient == "backward":
@@ -552,7 +758,11 @@ def _surface_sdf(s, orient):
     raise ValueError(orient)
 
 
-def _edge_sag(surface, sd):  # SphericalLensSDF.jl:421
+def _edge_sag(surface, sd):  # SphericalLensSDF.jl:421, AsphericalLensSDF.jl:462-471, CylindricalSDF.jl:184-185
+    if isinstance(surface, EvenAsphericalSurface):
+        return aspheric_equation(surface.diameter / 2, 1 / surface.radius, surface.conic_constant, surface.coefficients)
+    if isinstance(surface, CylindricalSurface):
+        return sd.thickness
     return sd.sag
 
 
@@ -594,8 +804,60 @@ def meniscus_lens_sdf(front_surface, front, back_surface, back, center_thickness
     return MeniscusLensSDF(convex_shape, cylinder, concave_shape, center_thickness)
 
 
+def _cyl_lens_shape(front_surface, back_surface, center_thickness):
+    """Lens(front::AbstractCylindricalSurface, back::AbstractCylindricalSurface, t, n): Lenses.jl:331-388, :432-446."""
+    if isinstance(front_surface, RectangularFlatSurface) and isinstance(back_surface, RectangularFlatSurface):
+        d_mid = min(front_surface.diameter, back_surface.diameter)
+        mid = BoxSDF(d_mid, center_thickness, d_mid)
+        translate3d(mid, [0, center_thickness / 2, 0])
+        return mid
+    l0 = center_thickness
+    front = _surface_sdf(front_surface, "forward")
+    l0 -= 0.0 if front is None else front.thickness
+    back = _surface_sdf(back_surface, "backward")
+    l0 -= 0.0 if back is None else back.thickness
+    # cylindric_lens_outer_parameters Lenses.jl:401-430
+    f, b = front_surface, back_surface
+    if isinstance(f, RectangularFlatSurface):
+        f, b = b, f
+    if isinstance(b, RectangularFlatSurface):
+        d_mid, md_mid, h = f.diameter, f.mechanical_diameter, f.height
+    else:
+        if f.height != b.height:
+            raise ValueError("height of front and back surface have to match for cylindric lenses")
+        d_mid, md_mid, h = min(f.diameter, b.diameter), max(f.mechanical_diameter, b.mechanical_diameter), f.height
+    if l0 <= 0:
+        raise ValueError("Lens parameters lead to a box section length of <= 0")
+    mid = BoxSDF(h, l0, d_mid)
+    translate3d(mid, [0, l0 / 2, 0])
+    if front is not None:
+        translate3d(mid, [0, front.thickness, 0])
+        mid = mid + front
+    if back is not None:
+        translate3d(back, [0, mid.thickness + back.thickness, 0])
+        mid = mid + back
+    shape = mid
+    if md_mid > d_mid:
+        ring_thickness = mid.thickness
+        ring_center = mid.pos[1] + ring_thickness / 2
+        if front is not None:
+            sg = _edge_sag(front_surface, front)
+            ring_thickness -= sg
+            ring_center += sg / 2
+        if back is not None:
+            sg = _edge_sag(back_surface, back)
+            ring_thickness += sg
+            ring_center += sg / 2
+        ring = RingSDF(d_mid / 2, (md_mid - d_mid) / 2, ring_thickness)
+        translate3d(ring, [0, ring_center, 0])
+        shape = shape + ring
+    return shape
+
+
 def lens_shape_from_surfaces(front_surface, back_surface, center_thickness):
     """Shape part of Lens(front_surface, back_surface, center_thickness, n): Lenses.jl:176-311."""
+    if isinstance(front_surface, (CylindricalSurface, RectangularFlatSurface)) or isinstance(back_surface, (CylindricalSurface, RectangularFlatSurface)):
+        return _cyl_lens_shape(front_surface, back_surface, center_thickness)
     if isinstance(front_surface, CircularFlatSurface) and isinstance(back_surface, CircularFlatSurface):
         return PlanoSurfaceSDF(center_thickness, min(front_surface.diameter, back_surface.diameter))  # Lenses.jl:304-311
     d_mid = min(front_surface.diameter, back_surface.diameter)

@@ -40,7 +40,7 @@ class CompiledScene:
         self.lambdas = np.array(sorted(set(float(l) for l in lambdas)), dtype=np.float64)
         self.shape_list = []   # python shape per shape id
         self._shape_ids = {}
-        shapes, children, tris = [], [], []
+        shapes, children, tris, coefs = [], [], [], []
         media, media_ids = [], {}
 
         def medium_of(fn):
@@ -79,6 +79,14 @@ class CompiledScene:
                 rec.child_begin = len(children)
                 rec.child_count = len(ids)
                 children.extend(ids)
+                c, r = s.world_bound()
+                if any(shapes[i].flags & sh.FLAG_INEXACT for i in ids):
+                    rec.flags |= sh.FLAG_INEXACT
+            elif s.kind in (sh.K_ASPH_CONVEX, sh.K_ASPH_CONCAVE):
+                rec.child_begin = len(coefs)
+                rec.child_count = len(s.coefficients)
+                coefs.extend(s.coefficients)
+                rec.flags |= sh.FLAG_INEXACT
                 c, r = s.world_bound()
             else:
                 c, r = s.world_bound()
@@ -131,6 +139,7 @@ class CompiledScene:
         self._children = np.array(children if children else [0], dtype=np.int32)
         self._tris = np.array(tris if tris else [[0.0] * 9], dtype=np.float64).reshape(-1)
         self._ntab = np.array(media if media else [[1.0] * max(1, len(self.lambdas))], dtype=np.float64).reshape(-1)
+        self._coefs = np.array(coefs if coefs else [0.0], dtype=np.float64)
         d = abi.SceneDesc()
         d.abi_version = abi.ABI_VERSION
         d.n_objects, d.n_shapes, d.n_children = len(objects), len(shapes), len(children)
@@ -141,6 +150,8 @@ class CompiledScene:
         d.tris = self._tris.ctypes.data_as(C.POINTER(C.c_double))
         d.n_table = self._ntab.ctypes.data_as(C.POINTER(C.c_double))
         d.lambdas = self.lambdas.ctypes.data_as(C.POINTER(C.c_double))
+        d.coefs = self._coefs.ctypes.data_as(C.POINTER(C.c_double))
+        d.n_coefs = len(coefs)
         k = dict(eps_srf=1e-9, eps_ray=1e-10, eps_ins=1.0, mt_keps=1e-9, mt_leps=1e-9, grad_h=1e-8, march_iters=1000)
         k.update(consts or {})
         for name, val in k.items():

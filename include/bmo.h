@@ -73,18 +73,26 @@ enum bmo_shape_kind {
     BMO_SHAPE_PRISM = 10,      /* PrimitiveSDF.jl:183-210     p = {hx, hy, hz}                     */
     BMO_SHAPE_MENISCUS = 11,   /* MeniscusLensSDF.jl:19-46    children = {convex, cylinder, concave} in the meniscus frame */
     BMO_SHAPE_POINT = 12,      /* test/runtests.jl:926-947 TestPointSDF: sdf = norm(p)             */
+    BMO_SHAPE_ASPH_CONVEX = 13,  /* AsphericalLensSDF.jl:19-28,309-327  p = {radius, conic, diameter, max_sag}; coefs = child range */
+    BMO_SHAPE_ASPH_CONCAVE = 14, /* AsphericalLensSDF.jl:85-96,329-349  p = {radius, conic, diameter, max_sag}; coefs = child range */
+    BMO_SHAPE_CYL_CONVEX = 15,   /* CylindricalSDF.jl:25-85   p = {radius, diameter, height}           */
+    BMO_SHAPE_CYL_CONCAVE = 16,  /* CylindricalSDF.jl:92-139  p = {radius, diameter, height}           */
     BMO_SHAPE_KIND_COUNT
 };
 
 #define BMO_SHAPE_NPARAM 8
+/* The SDF is a first-order distance ESTIMATE (aspheres: |z - z(r)| / |grad|), not 1-Lipschitz: only the bounding-sphere
+ * culls apply to it, not the running-t prune nor the union child skip (DESIGN.md "miss cull").  Unions inherit it. */
+#define BMO_SHAPE_FLAG_INEXACT 1
 
 typedef struct bmo_shape {
     int32_t kind;
-    int32_t child_begin;   /* index into bmo_scene_desc.children (UNION, MENISCUS) */
+    int32_t child_begin;   /* UNION, MENISCUS: index into bmo_scene_desc.children;
+                              ASPH_*: index into bmo_scene_desc.coefs (even aspheric coefficients A4, A6, ...) */
     int32_t child_count;
     int32_t tri_begin;     /* MESH: first triangle                                   */
     int32_t tri_count;
-    int32_t flags;         /* reserved, 0                                            */
+    int32_t flags;         /* BMO_SHAPE_FLAG_* */
     double pos[3];         /* position(shape)                                        */
     double dir[9];         /* orientation(shape), row-major 3x3                      */
     double tdir[9];        /* transposed_orientation(shape) (AbstractSDF.jl:20-27), row-major;
@@ -141,6 +149,7 @@ typedef struct bmo_scene_desc {
     const double* n_table;    /* [n_media][n_lambda]: n_obj(lambda) evaluated by the host
                                  (RefractiveIndexUtils.jl functors cannot cross a C ABI) */
     const double* lambdas;    /* [n_lambda] distinct wavelengths of the batch        */
+    const double* coefs;      /* [n_coefs] pooled aspheric coefficients              */
     /* tracing constants; the reference's compile-time values are the defaults */
     double eps_srf;        /* 1e-9  AbstractSDF.jl:1  */
     double eps_ray;        /* 1e-10 AbstractSDF.jl:2  */
@@ -149,7 +158,7 @@ typedef struct bmo_scene_desc {
     double mt_leps;        /* 1e-9  Mesh.jl:203       */
     double grad_h;         /* 1e-8  AbstractSDF.jl:83 */
     int32_t march_iters;   /* 1000  AbstractSDF.jl:105,135 */
-    int32_t reserved;
+    int32_t n_coefs;
 } bmo_scene_desc;
 
 typedef struct bmo_scene bmo_scene; /* opaque, immutable after create, shareable */

@@ -44,6 +44,7 @@ struct Scene {
     std::vector<double> tris;
     std::vector<double> n_table;
     std::vector<double> lambdas;
+    std::vector<double> coefs;
     int n_lambda = 0, n_detectors = 0;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int march_iters;
@@ -60,6 +61,7 @@ bool build_scene(const bmo_scene_desc* d, Scene& S) {
     S.tris.assign(d->tris, d->tris + 9 * (size_t)d->n_tris);
     S.n_table.assign(d->n_table, d->n_table + (size_t)d->n_media * d->n_lambda);
     S.lambdas.assign(d->lambdas, d->lambdas + d->n_lambda);
+    if (d->n_coefs > 0) S.coefs.assign(d->coefs, d->coefs + d->n_coefs);
     S.n_lambda = d->n_lambda;
     S.n_detectors = d->n_detectors;
     S.eps_srf = d->eps_srf;
@@ -86,6 +88,138 @@ T cyl2d(const V2<T>& d) {
     T mx = jmax(d.x, d.y);
     V2<T> m{jmax(d.x, 0.0), jmax(d.y, 0.0)};
     return jmin(mx, 0.0) + norm(m);
+}
+
+
+// ---- aspheres (AsphericalLensSDF.jl) ------------------------------------------------------------
+// x^n for integer n >= 0 by repeated squaring (Base.power_by_squaring; Julia >= 1.9 uses a compensated
+// variant for Float64 — last-ulp detail, unpinned)
+double ipow(double x, int n) {
+    if (n == 0) return 1.0;
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return x * x * x;
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= x;
+        x *= x;
+        n >>= 1;
+    }
+    return r;
+}
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+// aspheric_equation AsphericalLensSDF.jl:133-141
+double aspheric_equation(double r, double c, double k, const double* a, int na) {
+    double r2 = r * r;
+    double sqrt_arg = 1 - (1 + k) * (c * c) * r2;
+    if (sqrt_arg < 0) return kNaN;
+    double sum_a = 0.0;
+    for (int i = 1; i <= na; ++i) {
+        double term = a[i - 1] * ipow(r2, i);
+        sum_a = i == 1 ? term : sum_a + term;
+    }
+    return c * r2 / (1 + std::sqrt(sqrt_arg)) + sum_a;
+}
+// gradient_aspheric_equation :147-156 ; returns the first component (second is 1); NaN if undefined
+double gradient_aspheric_equation(double r, double c, double k, const double* a, int na) {
+    double Ri = 1 / c;
+    double sqrt_arg = 1 - (r * r) * (1 + k) / (Ri * Ri);
+    if (sqrt_arg < 0) return kNaN;
+    double sq = std::sqrt(sqrt_arg);
+    double gr = 2 * r / (Ri * (sq + 1)) + (r * r * r) * (1 + k) / ((Ri * Ri * Ri) * sq * ((sq + 1) * (sq + 1)));
+    double sum_r = 0.0;
+    for (int m = 1; m <= na; ++m) {
+        double term = 2 * m * a[m - 1] * ipow(r, 2 * (m - 1) + 1);
+        sum_r = m == 1 ? term : sum_r + term;
+    }
+    return -sum_r - gr;
+}
+double norm_g(double g1) { return std::sqrt(g1 * g1 + 1.0 * 1.0); }
+double jsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+// sd_line_segment :164-169
+double sd_line_segment(double px, double py, double ax, double ay, double bx, double by) {
+    double pax = px - ax, pay = py - ay, bax = bx - ax, bay = by - ay;
+    double h = (pax * bax + pay * bay) / (bax * bax + bay * bay);
+    h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
+    double ex = pax - h * bax, ey = pay - h * bay;
+    return std::sqrt(ex * ex + ey * ey);
+}
+// convex_aspheric_surface_distance :186-241
+double convex_aspheric_surface_distance(double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
+    double r2 = r * r, r2_bound = (d / 2) * (d / 2);
+    double zv = aspheric_equation(r, c, k, a, na);
+    double g = gradient_aspheric_equation(r, c, k, a, na);
+    double zb = aspheric_equation(d / 2, c, k, a, na);
+    double gb = gradient_aspheric_equation(d / 2, c, k, a, na);
+    if (std::isnan(zv) || std::isnan(g) || r2 > r2_bound) {
+        double e = r - jsign(r) * d / 2, db;
+        if (z < zb) db = std::sqrt(e * e + (z - zb) * (z - zb));
+        else if (zb < z && z < 0) db = std::sqrt(e * e);
+        else if (z > 0 && (jsign(c) == 1 && zb < 0)) db = std::sqrt(e * e + z * z);
+        else db = std::sqrt(e * e + (z - zb) * (z - zb));
+        return db / norm_g(gb);
+    }
+    double da = std::fabs(z - zv) / norm_g(g);
+    if (jsign(c) == 1 && zb < 0) {
+        double n = norm_g(gb);
+        double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, max_sag) / n;
+        double s2 = sd_line_segment(r, z, d / 2, max_sag, -d / 2, max_sag) / n;
+        double s3 = sd_line_segment(r, z, -d / 2, max_sag, -d / 2, zb) / n;
+        double m = jmin(jmin(jmin(da, s1), s2), s3);
+        if (zv < z && z < max_sag) return -m;
+        return m;
+    }
+    double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+    if (jsign(c) * zv < jsign(c) * z && jsign(c) * z < jsign(c) * zb) return -jmin(sdl, da);
+    return jmin(sdl, da);
+}
+// concave_aspheric_surface_distance :243-307
+double concave_aspheric_surface_distance(double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
+    double r2 = r * r, r2_bound = (d / 2) * (d / 2);
+    double zv = aspheric_equation(r, c, k, a, na);
+    double g = gradient_aspheric_equation(r, c, k, a, na);
+    double zb = aspheric_equation(d / 2, c, k, a, na);
+    double gb = gradient_aspheric_equation(d / 2, c, k, a, na);
+    if (std::isnan(zv) || std::isnan(g)) {
+        double e = r - jsign(r) * d / 2, db;
+        if (z < 0) db = std::sqrt(e * e + z * z);
+        else if (0 < z && z < zb) db = std::sqrt(e * e);
+        else db = std::sqrt(e * e + (z - zb) * (z - zb));
+        return db / norm_g(gb);
+    }
+    double da = std::fabs(z - zv) / norm_g(g);
+    if (max_sag > 0 && zb < 0) {
+        double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+        if (r2 > r2_bound) return sdl;
+        if (zb < z && z < zv) return -jmin(da, sdl);
+        if (zb > 0 && (0.0 < z && z < zv)) return -jmin(da, sdl);
+        return jmin(da, sdl);
+    }
+    double n = norm_g(gb);
+    double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, 0.0) / n;
+    double s2 = sd_line_segment(r, z, d / 2, 0.0, -d / 2, 0.0) / n;
+    double s3 = sd_line_segment(r, z, -d / 2, 0.0, -d / 2, zb) / n;
+    if (r2 > r2_bound) return jmin(jmin(s1, s2), s3);
+    double m = jmin(jmin(jmin(da, s1), s2), s3);
+    if (zb < 0 && (zv < z && z < 0.0)) return -m;
+    if (zb > 0 && (0.0 < z && z < zv)) return -m;
+    return m;
+}
+inline double asph_sdf(const Scene& S, const bmo_shape& s, const V3<double>& point) {  // :309-349 (op_revolve_z, AbstractSDF.jl:191-194)
+    V3<double> p = world_to_sdf(s, point);
+    double r = norm(V2<double>{p.x, p.z}) - 0.0;
+    const double* a = S.coefs.data() + s.child_begin;
+    if (s.kind == BMO_SHAPE_ASPH_CONVEX) return convex_aspheric_surface_distance(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
+    return concave_aspheric_surface_distance(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
+}
+inline Dual asph_sdf(const Scene&, const bmo_shape&, const V3<Dual>&) { return Dual{kNaN, {kNaN, kNaN, kNaN}}; }  // never differentiated (:5)
+
+// op_extrude_x AbstractSDF.jl:229-234
+template <class T>
+T op_extrude_x(const T& d2, const T& px, double height) {
+    T w1 = d2, w2 = jabs(px) - height;
+    V2<T> m{jmax(w1, 0.0), jmax(w2, 0.0)};
+    return jmin(jmax(w1, w2), 0.0) + norm(m);
 }
 
 template <class T>
@@ -169,6 +303,34 @@ T sdf_kind(const Scene& S, const bmo_shape& s, const V3<T>& point) {
             V2<T> m{jmax(d.x, 0.0), jmax(d.y, 0.0)};
             return norm(m) + jmin(jmax(d.x, d.y), 0.0);
         }
+        case BMO_SHAPE_ASPH_CONVEX:
+        case BMO_SHAPE_ASPH_CONCAVE: return asph_sdf(S, s, point);
+        case BMO_SHAPE_CYL_CONVEX: {  // CylindricalSDF.jl:62-85 (sdf_cut_disk :76-85)
+            V3<T> p = world_to_sdf(s, point);
+            double r = s.p[0], dia = s.p[1], height = s.p[2];
+            double h = std::sqrt(r * r - (dia / 2) * (dia / 2));
+            double w = std::sqrt(r * r - h * h);
+            V2<T> q{jabs(p.y), p.z};
+            double q1 = value(q.x), q2 = value(q.y);
+            double sv = jmax((h - r) * (q1 * q1) + (w * w) * (h + r - 2 * q2), h * q1 - w * q2);
+            T d2 = (sv < 0) ? norm(q) - r : ((q1 < w) ? h - q.y : norm(V2<T>{q.x - w, q.y - h}));
+            return op_extrude_x<T>(d2, p.x, height / 2);
+        }
+        case BMO_SHAPE_CYL_CONCAVE: {  // CylindricalSDF.jl:123-139
+            V3<T> p = world_to_sdf(s, point);
+            double radius = s.p[0], dia = s.p[1], height = s.p[2];
+            double ar = std::fabs(radius);
+            double sg = ar - std::sqrt(ar * ar - 0.25 * (dia * dia));
+            V3<T> ps{p.x + 0.0, p.y + (-radius), p.z + 0.0};
+            V2<T> a{norm(V2<T>{p.z, ps.y}), ps.x};
+            V2<T> d{jabs(a.x) - ar, jabs(a.y) - height / 2};
+            T c = cyl2d(d);
+            V3<T> pp{p.x + 0.0, p.y + (-sg / 2 * jsign(radius)), p.z + 0.0};
+            V3<T> q{jabs(pp.x) - height / 2, jabs(pp.y) - sg / 2, jabs(pp.z) - dia / 2};
+            V3<T> m{jmax(q.x, 0.0), jmax(q.y, 0.0), jmax(q.z, 0.0)};
+            T l = norm(m) + jmin(jmax(q.x, jmax(q.y, q.z)), 0.0);
+            return jmax(l, -c);
+        }
         case BMO_SHAPE_UNION: {  // UnionSDF.jl:53-56  minimum(sdf(_sdf, pos) for _sdf in s.sdfs)
             T best = sdf_shape<T>(S, S.children[s.child_begin], point);
             for (int c = 1; c < s.child_count; ++c) best = jmin(best, sdf_shape<T>(S, S.children[s.child_begin + c], point));
@@ -227,6 +389,7 @@ D3 normal3d_sdf(const Scene& S, int sid, const D3& pos) {
         }
         return normal3d_sdf(S, S.children[s.child_begin + best], pos);
     }
+    if (s.kind == BMO_SHAPE_ASPH_CONVEX || s.kind == BMO_SHAPE_ASPH_CONCAVE) return numeric_gradient(S, sid, pos);  // AsphericalLensSDF.jl:5
     return normal_fd(S, sid, pos);
 }
 

@@ -38,6 +38,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     S.children = d->children;
     S.tris = d->tris;
     S.n_table = d->n_table;
+    S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
     S.eps_srf = d->eps_srf;
@@ -88,7 +89,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             if (r.flags & 1) {
                 status = BMO_NODE_RMAX;
             } else {
-                X = tracing_step(S, r.ray.pos, r.ray.dir, r.hobj, r.hshape, c);
+                X = tracing_step<true>(S, r.ray.pos, r.ray.dir, r.hobj, r.hshape, c);
                 if (X.shape < 0) status = BMO_NODE_MISS;
                 else {
                     interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
@@ -238,6 +239,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
     S.children = d->children;
     S.tris = d->tris;
     S.n_table = d->n_table;
+    S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
     S.eps_srf = d->eps_srf;
@@ -298,7 +300,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             r.o.det_slot = -1;
             if (r.flags & 1) status = BMO_NODE_RMAX;
             else {
-                gauss_step(S, r.g, r.o, c);
+                gauss_step<true>(S, r.g, r.o, c);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;

@@ -92,3 +92,12 @@ def test_c5_32_elements(engine_ok, oracle):
     got, ref = run_both(oracle, system, c5_bundle(1536))
     compare(got, ref, 0.0, "c5")
     assert got.det_count.sum() > 0
+
+
+def test_aspheres_and_cylinder_lenses(engine_ok, oracle):
+    from scenes import disc_bundle
+    from test_oracle_kat3 import asphere_cylinder_scene
+
+    b = disc_bundle(2048, center=[0, -0.05, 0], direction=[0, 1, 0], diameter=0.044, e1=[1, 0, 0], jitter=5e-3)
+    got, ref = run_both(oracle, asphere_cylinder_scene(), b, r_max=40)
+    compare(got, ref, 0.0, "asph+cyl")
