@@ -1044,7 +1044,7 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
                 if (s.kind == BMO_SHAPE_MENISCUS && ck == BMO_SHAPE_MENISCUS) return fail(BMO_ERR_INVALID, "nested meniscus");
             }
         }
-        if ((s.kind == BMO_SHAPE_ASPH_CONVEX || s.kind == BMO_SHAPE_ASPH_CONCAVE) &&
+        if ((s.kind == BMO_SHAPE_ASPH_CONVEX || s.kind == BMO_SHAPE_ASPH_CONCAVE || s.kind == BMO_SHAPE_ACYL_CONVEX || s.kind == BMO_SHAPE_ACYL_CONCAVE) &&
             (s.child_begin < 0 || s.child_count < 0 || s.child_begin + s.child_count > d->n_coefs))
             return fail(BMO_ERR_INVALID, "aspheric coefficient range out of bounds");
         if (s.kind == BMO_SHAPE_MESH && (s.tri_begin < 0 || s.tri_begin + s.tri_count > d->n_tris))
@@ -1052,7 +1052,7 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     }
     bool has_split = false, has_asph = false;
     for (int i = 0; i < d->n_shapes; ++i)
-        if (d->shapes[i].kind >= BMO_SHAPE_ASPH_CONVEX && d->shapes[i].kind <= BMO_SHAPE_CYL_CONCAVE) has_asph = true;  // extended shapes
+        if (d->shapes[i].kind >= BMO_SHAPE_ASPH_CONVEX && d->shapes[i].kind <= BMO_SHAPE_ACYL_CONCAVE) has_asph = true;  // extended shapes
     for (int i = 0; i < d->n_objects; ++i) {
         const bmo_object& o = d->objects[i];
         if (o.kind < 0 || o.kind >= BMO_OBJ_KIND_COUNT) return fail(BMO_ERR_UNSUPPORTED, "unknown object kind");

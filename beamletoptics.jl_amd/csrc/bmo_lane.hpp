@@ -184,7 +184,31 @@ BMO_HD T slab2(const T& dx, const T& dy) {
 }
 
 
-// ------------------------------------------------------------------ aspheres (AsphericalLensSDF.jl:133-307)
+// ------------------------------------------------------------------ aspheres / acylinders
+// AsphericalLensSDF.jl:133-307, AcylindricalSDF.jl.  T = double (aspheres: never differentiated, :5) or Dual (acylinders
+// use the default normal_fd).  Extra ForwardDiff rules: Dual/Dual, Real/Dual, literal powers, run-time integer powers, clamp.
+BMO_HD Dual operator/(const Dual& x, const Dual& y) {
+    double ia = 1.0 / y.v, fb = -(x.v / (y.v * y.v));
+    return {x.v / y.v, (x.a * ia) + (y.a * fb), (x.b * ia) + (y.b * fb), (x.c * ia) + (y.c * fb)};
+}
+BMO_HD Dual operator/(double x, const Dual& y) {
+    double divv = x / y.v, f = -(divv / y.v);
+    return {divv, y.a * f, y.b * f, y.c * f};
+}
+BMO_HD bool lt(double a, double b) { return a < b; }
+BMO_HD bool lt(const Dual& a, double b) { return a.v < b; }
+BMO_HD bool lt(double a, const Dual& b) { return a < b.v; }
+BMO_HD bool lt(const Dual& a, const Dual& b) { return a.v < b.v; }
+BMO_HD double lit2(double x) { return x * x; }
+BMO_HD double lit3(double x) { return x * x * x; }
+BMO_HD Dual lit2(const Dual& x) {
+    double d = 2 * x.v;
+    return {x.v * x.v, x.a * d, x.b * d, x.c * d};
+}
+BMO_HD Dual lit3(const Dual& x) {
+    double d = 3 * (x.v * x.v);
+    return {x.v * x.v * x.v, x.a * d, x.b * d, x.c * d};
+}
 BMO_HD double ipow(double x, int n) {  // Base.power_by_squaring (small exponents multiply out like literal_pow)
     if (n == 0) return 1.0;
     if (n == 1) return x;
@@ -198,97 +222,112 @@ BMO_HD double ipow(double x, int n) {  // Base.power_by_squaring (small exponent
     }
     return r;
 }
+BMO_HD Dual ipow(const Dual& x, int n) {  // Dual(v^n, (partials * n) * v^(n-1)); zero partials short-cut
+    double ev = ipow(x.v, n);
+    if (n == 0 || (x.a == 0 && x.b == 0 && x.c == 0)) return {ev, 0, 0, 0};
+    double f = ipow(x.v, n - 1);
+    return {ev, (x.a * n) * f, (x.b * n) * f, (x.c * n) * f};
+}
 BMO_HD double knan() { return kinf() - kinf(); }
+BMO_HD double mknan(double) { return knan(); }
+BMO_HD Dual mknan(const Dual&) { return {knan(), knan(), knan(), knan()}; }
 BMO_HD double jsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+BMO_HD double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }
+BMO_HD Dual clamp01(const Dual& x) { return x.v > 1.0 ? Dual{1.0, 0, 0, 0} : (x.v < 0.0 ? Dual{0.0, 0, 0, 0} : x); }
 // aspheric_equation :133-141 and the first component of gradient_aspheric_equation :147-156, one pass over the coefficients
-BMO_HD void asph_eval(double r, double c, double k, const double* a, int na, double& z, double& g) {
-    const double r2 = r * r;
-    const double sa1 = 1 - (1 + k) * (c * c) * r2;
+template <class T>
+BMO_HD void asph_eval(const T& r, double c, double k, const double* a, int na, T& z, T& g) {
+    const T r2 = lit2(r);
+    const T sa1 = 1 - (1 + k) * (c * c) * r2;
     const double Ri = 1 / c;
-    const double sa2 = 1 - (r * r) * (1 + k) / (Ri * Ri);
-    double sum_a = 0.0, sum_r = 0.0;
+    const T sa2 = 1 - lit2(r) * (1 + k) / (Ri * Ri);
+    T sum_a = r2 * 0.0, sum_r = r * 0.0;
     BMO_NOUNROLL
     for (int i = 1; i <= na; ++i) {
-        const double ta = a[i - 1] * ipow(r2, i);
-        const double tr = 2 * i * a[i - 1] * ipow(r, 2 * (i - 1) + 1);
+        const T ta = a[i - 1] * ipow(r2, i);
+        const T tr = (2 * i * a[i - 1]) * ipow(r, 2 * (i - 1) + 1);
         sum_a = i == 1 ? ta : sum_a + ta;
         sum_r = i == 1 ? tr : sum_r + tr;
     }
-    z = sa1 < 0 ? knan() : c * r2 / (1 + sqrt(sa1)) + sum_a;
-    if (sa2 < 0) {
-        g = knan();
+    z = lt(sa1, 0.0) ? mknan(r) : c * r2 / (1 + jsqrt(sa1)) + sum_a;
+    if (lt(sa2, 0.0)) {
+        g = mknan(r);
     } else {
-        const double sq = sqrt(sa2);
-        const double gr = 2 * r / (Ri * (sq + 1)) + (r * r * r) * (1 + k) / ((Ri * Ri * Ri) * sq * ((sq + 1) * (sq + 1)));
+        const T sq = jsqrt(sa2);
+        const T gr = 2 * r / (Ri * (sq + 1)) + lit3(r) * (1 + k) / ((Ri * Ri * Ri) * sq * lit2(sq + 1));
         g = -sum_r - gr;
     }
 }
-BMO_HD double norm_g(double g1) { return sqrt(g1 * g1 + 1.0 * 1.0); }
-BMO_HD double sd_line_segment(double px, double py, double ax, double ay, double bx, double by) {  // :164-169
-    const double pax = px - ax, pay = py - ay, bax = bx - ax, bay = by - ay;
-    double h = (pax * bax + pay * bay) / (bax * bax + bay * bay);
-    h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
-    const double ex = pax - h * bax, ey = pay - h * bay;
-    return sqrt(ex * ex + ey * ey);
+template <class T>
+BMO_HD T norm_g(const T& g1) { return jsqrt(lit2(g1) + 1.0 * 1.0); }
+template <class T>
+BMO_HD T sd_line_segment(const T& px, const T& py, double ax, double ay, double bx, double by) {  // :164-169
+    const T pax = px - ax, pay = py - ay;
+    const double bax = bx - ax, bay = by - ay;
+    const T h = clamp01((pax * bax + pay * bay) / (bax * bax + bay * bay));
+    const T ex = pax - h * bax, ey = pay - h * bay;
+    return jsqrt(ex * ex + ey * ey);
 }
 // convex_/concave_aspheric_surface_distance :186-307
-BMO_HD double asph_distance(bool convex, double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
-    const double r2 = r * r, r2_bound = (d / 2) * (d / 2);
-    double zv, g, zb, gb;
-    asph_eval(r, c, k, a, na, zv, g);
-    asph_eval(d / 2, c, k, a, na, zb, gb);
-    const double e = r - jsign(r) * d / 2;
+template <class T>
+BMO_HD T asph_distance(bool convex, const T& r, const T& z, double c, double k, double d, const double* a, int na, double max_sag) {
+    const T r2 = lit2(r);
+    const double r2_bound = (d / 2) * (d / 2);
+    T zv, g;
+    double zb, gb;
+    asph_eval<T>(r, c, k, a, na, zv, g);
+    asph_eval<double>(d / 2, c, k, a, na, zb, gb);
+    const T e = r - jsign(val(r)) * d / 2;
+    const double ngb = norm_g<double>(gb);
     if (convex) {
-        if (isnan_(zv) || isnan_(g) || r2 > r2_bound) {
-            double db;
-            if (z < zb) db = sqrt(e * e + (z - zb) * (z - zb));
-            else if (zb < z && z < 0) db = sqrt(e * e);
-            else if (z > 0 && (jsign(c) == 1 && zb < 0)) db = sqrt(e * e + z * z);
-            else db = sqrt(e * e + (z - zb) * (z - zb));
-            return db / norm_g(gb);
+        if (isnan_(val(zv)) || isnan_(val(g)) || lt(r2_bound, r2)) {
+            T db;
+            if (lt(z, zb)) db = jsqrt(lit2(e) + lit2(z - zb));
+            else if (lt(zb, z) && lt(z, 0.0)) db = jsqrt(lit2(e));
+            else if (lt(0.0, z) && (jsign(c) == 1 && zb < 0)) db = jsqrt(lit2(e) + lit2(z));
+            else db = jsqrt(lit2(e) + lit2(z - zb));
+            return db / ngb;
         }
-        const double da = fabs(z - zv) / norm_g(g);
+        const T da = jabs(z - zv) / norm_g<T>(g);
         if (jsign(c) == 1 && zb < 0) {
-            const double n = norm_g(gb);
-            const double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, max_sag) / n;
-            const double s2 = sd_line_segment(r, z, d / 2, max_sag, -d / 2, max_sag) / n;
-            const double s3 = sd_line_segment(r, z, -d / 2, max_sag, -d / 2, zb) / n;
-            const double m = jmin(jmin(jmin(da, s1), s2), s3);
-            return (zv < z && z < max_sag) ? -m : m;
+            const T s1 = sd_line_segment<T>(r, z, d / 2, zb, d / 2, max_sag) / ngb;
+            const T s2 = sd_line_segment<T>(r, z, d / 2, max_sag, -d / 2, max_sag) / ngb;
+            const T s3 = sd_line_segment<T>(r, z, -d / 2, max_sag, -d / 2, zb) / ngb;
+            const T m = jmin(jmin(jmin(da, s1), s2), s3);
+            return (lt(zv, z) && lt(z, max_sag)) ? -m : m;
         }
-        const double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
-        if (jsign(c) * zv < jsign(c) * z && jsign(c) * z < jsign(c) * zb) return -jmin(sdl, da);
+        const T sdl = sd_line_segment<T>(r, z, d / 2, zb, -d / 2, zb) / ngb;
+        if (lt(jsign(c) * zv, jsign(c) * z) && lt(jsign(c) * z, jsign(c) * zb)) return -jmin(sdl, da);
         return jmin(sdl, da);
     }
-    if (isnan_(zv) || isnan_(g)) {
-        double db;
-        if (z < 0) db = sqrt(e * e + z * z);
-        else if (0 < z && z < zb) db = sqrt(e * e);
-        else db = sqrt(e * e + (z - zb) * (z - zb));
-        return db / norm_g(gb);
+    if (isnan_(val(zv)) || isnan_(val(g))) {
+        T db;
+        if (lt(z, 0.0)) db = jsqrt(lit2(e) + lit2(z));
+        else if (lt(0.0, z) && lt(z, zb)) db = jsqrt(lit2(e));
+        else db = jsqrt(lit2(e) + lit2(z - zb));
+        return db / ngb;
     }
-    const double da = fabs(z - zv) / norm_g(g);
+    const T da = jabs(z - zv) / norm_g<T>(g);
     if (max_sag > 0 && zb < 0) {
-        const double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
-        if (r2 > r2_bound) return sdl;
-        if (zb < z && z < zv) return -jmin(da, sdl);
-        if (zb > 0 && (0.0 < z && z < zv)) return -jmin(da, sdl);
+        const T sdl = sd_line_segment<T>(r, z, d / 2, zb, -d / 2, zb) / ngb;
+        if (lt(r2_bound, r2)) return sdl;
+        if (lt(zb, z) && lt(z, zv)) return -jmin(da, sdl);
+        if (zb > 0 && (lt(0.0, z) && lt(z, zv))) return -jmin(da, sdl);
         return jmin(da, sdl);
     }
-    const double n = norm_g(gb);
-    const double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, 0.0) / n;
-    const double s2 = sd_line_segment(r, z, d / 2, 0.0, -d / 2, 0.0) / n;
-    const double s3 = sd_line_segment(r, z, -d / 2, 0.0, -d / 2, zb) / n;
-    if (r2 > r2_bound) return jmin(jmin(s1, s2), s3);
-    const double m = jmin(jmin(jmin(da, s1), s2), s3);
-    if (zb < 0 && (zv < z && z < 0.0)) return -m;
-    if (zb > 0 && (0.0 < z && z < zv)) return -m;
+    const T s1 = sd_line_segment<T>(r, z, d / 2, zb, d / 2, 0.0) / ngb;
+    const T s2 = sd_line_segment<T>(r, z, d / 2, 0.0, -d / 2, 0.0) / ngb;
+    const T s3 = sd_line_segment<T>(r, z, -d / 2, 0.0, -d / 2, zb) / ngb;
+    if (lt(r2_bound, r2)) return jmin(jmin(s1, s2), s3);
+    const T m = jmin(jmin(jmin(da, s1), s2), s3);
+    if (zb < 0 && (lt(zv, z) && lt(z, 0.0))) return -m;
+    if (zb > 0 && (lt(0.0, z) && lt(z, zv))) return -m;
     return m;
 }
 // aspheres are never differentiated (normal3d = numeric_gradient, AsphericalLensSDF.jl:5): the Dual overload returns NaN,
 // which sends normal_any straight to the same central-difference stencil.
 BMO_HD double asph_leaf(const bmo_shape& s, const double* coefs, double r, double y) {
-    return asph_distance(s.kind == BMO_SHAPE_ASPH_CONVEX, r, y, 1 / s.p[0], s.p[1], s.p[2], coefs + s.child_begin, s.child_count, s.p[3]);
+    return asph_distance<double>(s.kind == BMO_SHAPE_ASPH_CONVEX, r, y, 1 / s.p[0], s.p[1], s.p[2], coefs + s.child_begin, s.child_count, s.p[3]);
 }
 BMO_HD Dual asph_leaf(const bmo_shape&, const double*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
 
@@ -369,6 +408,12 @@ BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt, const double* coefs) {
         }
     }
     if constexpr (ASPH) {
+        if (kind == BMO_SHAPE_ACYL_CONVEX || kind == BMO_SHAPE_ACYL_CONCAVE) {  // AcylindricalSDF.jl:55-74, :122-141
+            const double height = s.p[2];
+            T d2 = asph_distance<T>(kind == BMO_SHAPE_ACYL_CONVEX, p.z, p.y, 1 / s.p[0], s.p[3], s.p[1], coefs + s.child_begin, s.child_count, s.p[4]);
+            T w2 = jabs(p.x) - height / 2;
+            return jmin(jmax(d2, w2), 0.0) + norm2(jmax(d2, 0.0), jmax(w2, 0.0));
+        }
         if (kind == BMO_SHAPE_CYL_CONVEX) {  // CylindricalSDF.jl:62-85: op_extrude_x of sdf_cut_disk
             const double r = s.p[0], dia = s.p[1], height = s.p[2];
             const double h = sqrt(r * r - (dia / 2) * (dia / 2));

@@ -735,6 +735,8 @@ def _surface_sdf(s, orient):
         if orient == "backward":
             return ConcaveAsphericalSurfaceSDF(*args) if s.radius > 0 else ConvexAsphericalSurfaceSDF(*args)
         raise ValueError("aspheric meniscus lenses are not supported by the reference either")
+    if isinstance(s, AcylindricalSurface):
+        return _acyl_surface_sdf(s, orient)
     if isinstance(s, CylindricalSurface):  # CylindricalSDF.jl:187-215
         if orient == "forward":
             return ConvexCylinderSDF(s.radius, s.diameter, s.height) if s.radius > 0 else ConcaveCylinderSDF(s.radius, s.diameter, s.height)
@@ -761,6 +763,8 @@ def _surface_sdf(s, orient):
 def _edge_sag(surface, sd):  # SphericalLensSDF.jl:421, AsphericalLensSDF.jl:462-471, CylindricalSDF.jl:184-185
     if isinstance(surface, EvenAsphericalSurface):
         return aspheric_equation(surface.diameter / 2, 1 / surface.radius, surface.conic_constant, surface.coefficients)
+    if isinstance(surface, AcylindricalSurface):
+        return _acyl_edge_sag(surface)
     if isinstance(surface, CylindricalSurface):
         return sd.thickness
     return sd.sag
@@ -926,3 +930,12 @@ def lens_shape_from_surfaces(front_surface, back_surface, center_thickness):
         translate3d(ring, [0, outer_center, 0])
         shape = shape + ring
     return shape
+
+
+# acylinders live in their own module (AcylindricalSDF.jl); import last so they can subclass the types above
+import sys as _sys  # noqa: E402
+
+from . import acylinders as _acyl  # noqa: E402
+
+K_ACYL_CONVEX, K_ACYL_CONCAVE = _acyl.K_ACYL_CONVEX, _acyl.K_ACYL_CONCAVE
+AconvexCylinderSDF, AconcaveCylinderSDF, AcylindricalSurface, _acyl_surface_sdf, _acyl_edge_sag = _acyl.make(_sys.modules[__name__])

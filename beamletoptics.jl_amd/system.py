@@ -82,7 +82,7 @@ class CompiledScene:
                 c, r = s.world_bound()
                 if any(shapes[i].flags & sh.FLAG_INEXACT for i in ids):
                     rec.flags |= sh.FLAG_INEXACT
-            elif s.kind in (sh.K_ASPH_CONVEX, sh.K_ASPH_CONCAVE):
+            elif s.kind in (sh.K_ASPH_CONVEX, sh.K_ASPH_CONCAVE, sh.K_ACYL_CONVEX, sh.K_ACYL_CONCAVE):
                 rec.child_begin = len(coefs)
                 rec.child_count = len(s.coefficients)
                 coefs.extend(s.coefficients)

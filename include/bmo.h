@@ -77,6 +77,8 @@ enum bmo_shape_kind {
     BMO_SHAPE_ASPH_CONCAVE = 14, /* AsphericalLensSDF.jl:85-96,329-349  p = {radius, conic, diameter, max_sag}; coefs = child range */
     BMO_SHAPE_CYL_CONVEX = 15,   /* CylindricalSDF.jl:25-85   p = {radius, diameter, height}           */
     BMO_SHAPE_CYL_CONCAVE = 16,  /* CylindricalSDF.jl:92-139  p = {radius, diameter, height}           */
+    BMO_SHAPE_ACYL_CONVEX = 17,  /* AcylindricalSDF.jl:16-74   p = {radius, diameter, height, conic, max_sag}; coefs = child range */
+    BMO_SHAPE_ACYL_CONCAVE = 18, /* AcylindricalSDF.jl:83-141  p = {radius, diameter, height, conic, max_sag}; coefs = child range */
     BMO_SHAPE_KIND_COUNT
 };
 

@@ -91,116 +91,111 @@ T cyl2d(const V2<T>& d) {
 }
 
 
-// ---- aspheres (AsphericalLensSDF.jl) ------------------------------------------------------------
-// x^n for integer n >= 0 by repeated squaring (Base.power_by_squaring; Julia >= 1.9 uses a compensated
-// variant for Float64 — last-ulp detail, unpinned)
-double ipow(double x, int n) {
-    if (n == 0) return 1.0;
-    if (n == 1) return x;
-    if (n == 2) return x * x;
-    if (n == 3) return x * x * x;
-    double r = 1.0;
-    while (n > 0) {
-        if (n & 1) r *= x;
-        x *= x;
-        n >>= 1;
-    }
-    return r;
-}
+// ---- aspheres / acylinders (AsphericalLensSDF.jl, AcylindricalSDF.jl), T = double or Dual ---------------------
 const double kNaN = std::numeric_limits<double>::quiet_NaN();
 // aspheric_equation AsphericalLensSDF.jl:133-141
-double aspheric_equation(double r, double c, double k, const double* a, int na) {
-    double r2 = r * r;
-    double sqrt_arg = 1 - (1 + k) * (c * c) * r2;
-    if (sqrt_arg < 0) return kNaN;
-    double sum_a = 0.0;
+template <class T>
+T aspheric_equation(const T& r, double c, double k, const double* a, int na) {
+    T r2 = lit2(r);
+    T sqrt_arg = 1 - (1 + k) * (c * c) * r2;
+    if (sqrt_arg < 0.0) return mknan(r);
+    T sum_a = r2 * 0.0;
     for (int i = 1; i <= na; ++i) {
-        double term = a[i - 1] * ipow(r2, i);
+        T term = a[i - 1] * ipow(r2, i);
         sum_a = i == 1 ? term : sum_a + term;
     }
-    return c * r2 / (1 + std::sqrt(sqrt_arg)) + sum_a;
+    return c * r2 / (1 + jsqrt(sqrt_arg)) + sum_a;
 }
-// gradient_aspheric_equation :147-156 ; returns the first component (second is 1); NaN if undefined
-double gradient_aspheric_equation(double r, double c, double k, const double* a, int na) {
+// gradient_aspheric_equation :147-156 ; first component (the second is 1); NaN if undefined
+template <class T>
+T gradient_aspheric_equation(const T& r, double c, double k, const double* a, int na) {
     double Ri = 1 / c;
-    double sqrt_arg = 1 - (r * r) * (1 + k) / (Ri * Ri);
-    if (sqrt_arg < 0) return kNaN;
-    double sq = std::sqrt(sqrt_arg);
-    double gr = 2 * r / (Ri * (sq + 1)) + (r * r * r) * (1 + k) / ((Ri * Ri * Ri) * sq * ((sq + 1) * (sq + 1)));
-    double sum_r = 0.0;
+    T sqrt_arg = 1 - lit2(r) * (1 + k) / (Ri * Ri);
+    if (sqrt_arg < 0.0) return mknan(r);
+    T sq = jsqrt(sqrt_arg);
+    T gr = 2 * r / (Ri * (sq + 1)) + lit3(r) * (1 + k) / ((Ri * Ri * Ri) * sq * lit2(sq + 1));
+    T sum_r = r * 0.0;
     for (int m = 1; m <= na; ++m) {
-        double term = 2 * m * a[m - 1] * ipow(r, 2 * (m - 1) + 1);
+        T term = (2 * m * a[m - 1]) * ipow(r, 2 * (m - 1) + 1);
         sum_r = m == 1 ? term : sum_r + term;
     }
     return -sum_r - gr;
 }
-double norm_g(double g1) { return std::sqrt(g1 * g1 + 1.0 * 1.0); }
+template <class T>
+T norm_g(const T& g1) { return jsqrt(lit2(g1) + 1.0 * 1.0); }
 double jsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 // sd_line_segment :164-169
-double sd_line_segment(double px, double py, double ax, double ay, double bx, double by) {
-    double pax = px - ax, pay = py - ay, bax = bx - ax, bay = by - ay;
-    double h = (pax * bax + pay * bay) / (bax * bax + bay * bay);
-    h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
-    double ex = pax - h * bax, ey = pay - h * bay;
-    return std::sqrt(ex * ex + ey * ey);
+template <class T>
+T sd_line_segment(const T& px, const T& py, double ax, double ay, double bx, double by) {
+    T pax = px - ax, pay = py - ay;
+    double bax = bx - ax, bay = by - ay;
+    T h = clamp01((pax * bax + pay * bay) / (bax * bax + bay * bay));
+    T ex = pax - h * bax, ey = pay - h * bay;
+    return jsqrt(ex * ex + ey * ey);
 }
 // convex_aspheric_surface_distance :186-241
-double convex_aspheric_surface_distance(double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
-    double r2 = r * r, r2_bound = (d / 2) * (d / 2);
-    double zv = aspheric_equation(r, c, k, a, na);
-    double g = gradient_aspheric_equation(r, c, k, a, na);
-    double zb = aspheric_equation(d / 2, c, k, a, na);
-    double gb = gradient_aspheric_equation(d / 2, c, k, a, na);
-    if (std::isnan(zv) || std::isnan(g) || r2 > r2_bound) {
-        double e = r - jsign(r) * d / 2, db;
-        if (z < zb) db = std::sqrt(e * e + (z - zb) * (z - zb));
-        else if (zb < z && z < 0) db = std::sqrt(e * e);
-        else if (z > 0 && (jsign(c) == 1 && zb < 0)) db = std::sqrt(e * e + z * z);
-        else db = std::sqrt(e * e + (z - zb) * (z - zb));
-        return db / norm_g(gb);
+template <class T>
+T convex_aspheric_surface_distance(const T& r, const T& z, double c, double k, double d, const double* a, int na, double max_sag) {
+    T r2 = lit2(r);
+    double r2_bound = (d / 2) * (d / 2);
+    T zv = aspheric_equation<T>(r, c, k, a, na);
+    T g = gradient_aspheric_equation<T>(r, c, k, a, na);
+    double zb = aspheric_equation<double>(d / 2, c, k, a, na);
+    double gb = gradient_aspheric_equation<double>(d / 2, c, k, a, na);
+    if (jisnan(zv) || jisnan(g) || r2 > r2_bound) {
+        T e = r - jsignv(r) * d / 2;
+        T db = e;
+        if (z < zb) db = jsqrt(lit2(e) + lit2(z - zb));
+        else if (zb < z && z < 0.0) db = jsqrt(lit2(e));
+        else if (z > 0.0 && (jsign(c) == 1 && zb < 0)) db = jsqrt(lit2(e) + lit2(z));
+        else db = jsqrt(lit2(e) + lit2(z - zb));
+        return db / norm_g<double>(gb);
     }
-    double da = std::fabs(z - zv) / norm_g(g);
+    T da = jabs(z - zv) / norm_g<T>(g);
     if (jsign(c) == 1 && zb < 0) {
-        double n = norm_g(gb);
-        double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, max_sag) / n;
-        double s2 = sd_line_segment(r, z, d / 2, max_sag, -d / 2, max_sag) / n;
-        double s3 = sd_line_segment(r, z, -d / 2, max_sag, -d / 2, zb) / n;
-        double m = jmin(jmin(jmin(da, s1), s2), s3);
+        double n = norm_g<double>(gb);
+        T s1 = sd_line_segment<T>(r, z, d / 2, zb, d / 2, max_sag) / n;
+        T s2 = sd_line_segment<T>(r, z, d / 2, max_sag, -d / 2, max_sag) / n;
+        T s3 = sd_line_segment<T>(r, z, -d / 2, max_sag, -d / 2, zb) / n;
+        T m = jmin(jmin(jmin(da, s1), s2), s3);
         if (zv < z && z < max_sag) return -m;
         return m;
     }
-    double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+    T sdl = sd_line_segment<T>(r, z, d / 2, zb, -d / 2, zb) / norm_g<double>(gb);
     if (jsign(c) * zv < jsign(c) * z && jsign(c) * z < jsign(c) * zb) return -jmin(sdl, da);
     return jmin(sdl, da);
 }
 // concave_aspheric_surface_distance :243-307
-double concave_aspheric_surface_distance(double r, double z, double c, double k, double d, const double* a, int na, double max_sag) {
-    double r2 = r * r, r2_bound = (d / 2) * (d / 2);
-    double zv = aspheric_equation(r, c, k, a, na);
-    double g = gradient_aspheric_equation(r, c, k, a, na);
-    double zb = aspheric_equation(d / 2, c, k, a, na);
-    double gb = gradient_aspheric_equation(d / 2, c, k, a, na);
-    if (std::isnan(zv) || std::isnan(g)) {
-        double e = r - jsign(r) * d / 2, db;
-        if (z < 0) db = std::sqrt(e * e + z * z);
-        else if (0 < z && z < zb) db = std::sqrt(e * e);
-        else db = std::sqrt(e * e + (z - zb) * (z - zb));
-        return db / norm_g(gb);
+template <class T>
+T concave_aspheric_surface_distance(const T& r, const T& z, double c, double k, double d, const double* a, int na, double max_sag) {
+    T r2 = lit2(r);
+    double r2_bound = (d / 2) * (d / 2);
+    T zv = aspheric_equation<T>(r, c, k, a, na);
+    T g = gradient_aspheric_equation<T>(r, c, k, a, na);
+    double zb = aspheric_equation<double>(d / 2, c, k, a, na);
+    double gb = gradient_aspheric_equation<double>(d / 2, c, k, a, na);
+    if (jisnan(zv) || jisnan(g)) {
+        T e = r - jsignv(r) * d / 2;
+        T db = e;
+        if (z < 0.0) db = jsqrt(lit2(e) + lit2(z));
+        else if (0.0 < z && z < zb) db = jsqrt(lit2(e));
+        else db = jsqrt(lit2(e) + lit2(z - zb));
+        return db / norm_g<double>(gb);
     }
-    double da = std::fabs(z - zv) / norm_g(g);
+    T da = jabs(z - zv) / norm_g<T>(g);
     if (max_sag > 0 && zb < 0) {
-        double sdl = sd_line_segment(r, z, d / 2, zb, -d / 2, zb) / norm_g(gb);
+        T sdl = sd_line_segment<T>(r, z, d / 2, zb, -d / 2, zb) / norm_g<double>(gb);
         if (r2 > r2_bound) return sdl;
         if (zb < z && z < zv) return -jmin(da, sdl);
         if (zb > 0 && (0.0 < z && z < zv)) return -jmin(da, sdl);
         return jmin(da, sdl);
     }
-    double n = norm_g(gb);
-    double s1 = sd_line_segment(r, z, d / 2, zb, d / 2, 0.0) / n;
-    double s2 = sd_line_segment(r, z, d / 2, 0.0, -d / 2, 0.0) / n;
-    double s3 = sd_line_segment(r, z, -d / 2, 0.0, -d / 2, zb) / n;
+    double n = norm_g<double>(gb);
+    T s1 = sd_line_segment<T>(r, z, d / 2, zb, d / 2, 0.0) / n;
+    T s2 = sd_line_segment<T>(r, z, d / 2, 0.0, -d / 2, 0.0) / n;
+    T s3 = sd_line_segment<T>(r, z, -d / 2, 0.0, -d / 2, zb) / n;
     if (r2 > r2_bound) return jmin(jmin(s1, s2), s3);
-    double m = jmin(jmin(jmin(da, s1), s2), s3);
+    T m = jmin(jmin(jmin(da, s1), s2), s3);
     if (zb < 0 && (zv < z && z < 0.0)) return -m;
     if (zb > 0 && (0.0 < z && z < zv)) return -m;
     return m;
@@ -209,8 +204,8 @@ inline double asph_sdf(const Scene& S, const bmo_shape& s, const V3<double>& poi
     V3<double> p = world_to_sdf(s, point);
     double r = norm(V2<double>{p.x, p.z}) - 0.0;
     const double* a = S.coefs.data() + s.child_begin;
-    if (s.kind == BMO_SHAPE_ASPH_CONVEX) return convex_aspheric_surface_distance(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
-    return concave_aspheric_surface_distance(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
+    if (s.kind == BMO_SHAPE_ASPH_CONVEX) return convex_aspheric_surface_distance<double>(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
+    return concave_aspheric_surface_distance<double>(r, p.y, 1 / s.p[0], s.p[1], s.p[2], a, s.child_count, s.p[3]);
 }
 inline Dual asph_sdf(const Scene&, const bmo_shape&, const V3<Dual>&) { return Dual{kNaN, {kNaN, kNaN, kNaN}}; }  // never differentiated (:5)
 
@@ -305,6 +300,15 @@ T sdf_kind(const Scene& S, const bmo_shape& s, const V3<T>& point) {
         }
         case BMO_SHAPE_ASPH_CONVEX:
         case BMO_SHAPE_ASPH_CONCAVE: return asph_sdf(S, s, point);
+        case BMO_SHAPE_ACYL_CONVEX:
+        case BMO_SHAPE_ACYL_CONCAVE: {  // AcylindricalSDF.jl:55-74, :122-141: op_extrude_x of the 2D aspheric profile
+            V3<T> p = world_to_sdf(s, point);
+            const double* a = S.coefs.data() + s.child_begin;
+            double c = 1 / s.p[0], dia = s.p[1], height = s.p[2], k = s.p[3], max_sag = s.p[4];
+            T d2 = s.kind == BMO_SHAPE_ACYL_CONVEX ? convex_aspheric_surface_distance<T>(p.z, p.y, c, k, dia, a, s.child_count, max_sag)
+                                                   : concave_aspheric_surface_distance<T>(p.z, p.y, c, k, dia, a, s.child_count, max_sag);
+            return op_extrude_x<T>(d2, p.x, height / 2);
+        }
         case BMO_SHAPE_CYL_CONVEX: {  // CylindricalSDF.jl:62-85 (sdf_cut_disk :76-85)
             V3<T> p = world_to_sdf(s, point);
             double r = s.p[0], dia = s.p[1], height = s.p[2];

@@ -101,6 +101,62 @@ inline Dual jmin(const Dual& x, double y) {
     return Dual{jmin(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
 }
 
+
+// ---- additional Dual rules used by the aspheric / acylindric SDFs (ForwardDiff dual.jl) ----------------------
+// Dual / Dual: Dual(vx/vy, _div_partials(px, py, vx, vy)), _div_partials(a, b, av, bv) = _mul_partials(a, b, inv(bv), -(av/(bv*bv)))
+inline Dual operator/(const Dual& x, const Dual& y) {
+    double ia = 1.0 / y.v, fb = -(x.v / (y.v * y.v));
+    return Dual{x.v / y.v, {(x.p[0] * ia) + (y.p[0] * fb), (x.p[1] * ia) + (y.p[1] * fb), (x.p[2] * ia) + (y.p[2] * fb)}};
+}
+// Real / Dual: divv = x / v; Dual(divv, -(divv / v) * partials(y))
+inline Dual operator/(double x, const Dual& y) {
+    double divv = x / y.v, f = -(divv / y.v);
+    return Dual{divv, {y.p[0] * f, y.p[1] * f, y.p[2] * f}};
+}
+inline bool operator>(const Dual& a, const Dual& b) { return a.v > b.v; }
+inline bool operator<(double a, const Dual& b) { return a < b.v; }
+inline bool operator>(double a, const Dual& b) { return a > b.v; }
+// literal_pow(^, x::Dual, Val(y)), y = 2, 3: Dual(v^y, (y * v^(y-1)) * partials)
+inline double lit2(double x) { return x * x; }
+inline double lit3(double x) { return x * x * x; }
+inline Dual lit2(const Dual& x) {
+    double d = 2 * x.v;
+    return Dual{x.v * x.v, {x.p[0] * d, x.p[1] * d, x.p[2] * d}};
+}
+inline Dual lit3(const Dual& x) {
+    double d = 3 * (x.v * x.v);
+    return Dual{x.v * x.v * x.v, {x.p[0] * d, x.p[1] * d, x.p[2] * d}};
+}
+// x^n, n a run-time Int >= 1: power by squaring for reals; Dual: Dual(v^n, (partials * n) * v^(n-1)), zero partials short-cut
+inline double ipow(double x, int n) {
+    if (n == 0) return 1.0;
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return x * x * x;
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= x;
+        x *= x;
+        n >>= 1;
+    }
+    return r;
+}
+inline Dual ipow(const Dual& x, int n) {
+    double ev = ipow(x.v, n);
+    if (n == 0 || (x.p[0] == 0 && x.p[1] == 0 && x.p[2] == 0)) return Dual{ev, {0, 0, 0}};
+    double f = ipow(x.v, n - 1);
+    return Dual{ev, {(x.p[0] * n) * f, (x.p[1] * n) * f, (x.p[2] * n) * f}};
+}
+inline bool jisnan(double x) { return std::isnan(x); }
+inline bool jisnan(const Dual& x) { return std::isnan(x.v); }
+inline double jsignv(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+inline double jsignv(const Dual& x) { return jsignv(x.v); }
+// clamp(x, 0.0, 1.0) (Base): ifelse(x > hi, hi, ifelse(x < lo, lo, x)); constants carry zero partials
+inline double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }
+inline Dual clamp01(const Dual& x) { return x.v > 1.0 ? Dual{1.0, {0, 0, 0}} : (x.v < 0.0 ? Dual{0.0, {0, 0, 0}} : x); }
+inline Dual mknan(const Dual&) { double n = std::numeric_limits<double>::quiet_NaN(); return Dual{n, {n, n, n}}; }
+inline double mknan(double) { return std::numeric_limits<double>::quiet_NaN(); }
+
 // ---------------------------------------------------------------------------
 template <class T>
 struct V3 {

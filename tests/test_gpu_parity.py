@@ -101,3 +101,20 @@ def test_aspheres_and_cylinder_lenses(engine_ok, oracle):
     b = disc_bundle(2048, center=[0, -0.05, 0], direction=[0, 1, 0], diameter=0.044, e1=[1, 0, 0], jitter=5e-3)
     got, ref = run_both(oracle, asphere_cylinder_scene(), b, r_max=40)
     compare(got, ref, 0.0, "asph+cyl")
+
+
+def test_acylinder_lenses(engine_ok, oracle):
+    import math
+
+    from scenes import disc_bundle, mm
+    from test_oracle_kat3 import AYL
+
+    a1 = bmo.Lens(bmo.AcylindricalSurface(15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.777)
+    a2 = bmo.Lens(bmo.AcylindricalSurface(-15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.6)
+    bmo.translate3d(a2, [0, 20 * mm, 0])
+    bmo.yrotate3d(a2, math.radians(35))
+    det = bmo.Spotdetector(80 * mm)
+    bmo.translate3d(det, [0, 60 * mm, 0])
+    b = disc_bundle(2048, center=[0, -0.03, 0], direction=[0, 1, 0], diameter=22 * mm, e1=[1, 0, 0], jitter=5e-3)
+    got, ref = run_both(oracle, bmo.System([a1, a2, det]), b, r_max=40)
+    compare(got, ref, 0.0, "acyl")

@@ -68,3 +68,31 @@ def test_lane_code_matches_oracle_on_aspheres_and_cylinders(oracle):
     assert ref.det_count[0] > 300 and int(ref.node_nseg.max()) == 7
     off = bmo.CompiledScene(system, b.lambdas, cull=False)
     compare(emu_trace(off, b, 40), ref, 0.0, "asph+cyl cull-off")
+
+
+AYL = [0, 1.1926075e-5 * (1e3) ** 3, -2.9323497e-9 * (1e3) ** 5, -1.8718889e-11 * (1e3) ** 7, -1.7009961e-14 * (1e3) ** 9,
+       3.5481542e-17 * (1e3) ** 11, 6.5241296e-20 * (1e3) ** 13]  # Thorlabs AYL2520
+
+
+def test_acylinder_lenses(oracle):  # runtests.jl:1744-1785
+    lens = bmo.Lens(bmo.AcylindricalSurface(15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.777)
+    assert abs(lens.thickness - 7.5e-3) <= 1.5e-8 * 7.5e-3
+    assert abs(working_distance(oracle, lens, 0.05 * 25e-3 / 2) - 15.8e-3) <= 1e-4
+    lens = bmo.Lens(bmo.AcylindricalSurface(-15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.777)
+    assert abs(lens.thickness - 7.5e-3) <= 1.5e-8 * 7.5e-3
+
+
+def test_lane_code_matches_oracle_on_acylinders(oracle):
+    a1 = bmo.Lens(bmo.AcylindricalSurface(15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.777)
+    a2 = bmo.Lens(bmo.AcylindricalSurface(-15.538e-3, 25e-3, 50e-3, -1.0, AYL), 7.5e-3, lambda n: 1.6)
+    bmo.translate3d(a2, [0, 20 * mm, 0])
+    bmo.yrotate3d(a2, math.radians(35))
+    bmo.xrotate3d(a1, math.radians(1.5))
+    det = bmo.Spotdetector(80 * mm)
+    bmo.translate3d(det, [0, 60 * mm, 0])
+    system = bmo.System([a1, a2, det])
+    b = disc_bundle(300, center=[0, -0.03, 0], direction=[0, 1, 0], diameter=22 * mm, e1=[1, 0, 0], jitter=5e-3)
+    sc = bmo.CompiledScene(system, b.lambdas)
+    ref = oracle.trace(sc, b, 40, threads=8)
+    compare(emu_trace(sc, b, 40), ref, 0.0, "acyl")
+    assert ref.det_count[0] > 200
