@@ -71,15 +71,16 @@ struct BlobHeader {
     uint32_t has_asphere, pad;
 };
 
-__host__ __device__ inline SceneView view_of(const char* blob) {
-    const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+template <class CharPtr>
+__host__ __device__ inline SceneView view_of(CharPtr blob) {
+    auto h = (const BMO_AS BlobHeader*)(blob);
     SceneView S;
-    S.objects = reinterpret_cast<const bmo_object*>(blob + h->off_objects);
-    S.shapes = reinterpret_cast<const bmo_shape*>(blob + h->off_shapes);
-    S.children = reinterpret_cast<const int32_t*>(blob + h->off_children);
-    S.tris = reinterpret_cast<const double*>(blob + h->off_tris);
-    S.n_table = reinterpret_cast<const double*>(blob + h->off_ntable);
-    S.coefs = reinterpret_cast<const double*>(blob + h->off_coefs);
+    S.objects = (CObject*)(blob + h->off_objects);
+    S.shapes = (CShape*)(blob + h->off_shapes);
+    S.children = (CInt*)(blob + h->off_children);
+    S.tris = (CDouble*)(blob + h->off_tris);
+    S.n_table = (CDouble*)(blob + h->off_ntable);
+    S.coefs = (CDouble*)(blob + h->off_coefs);
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -224,9 +225,13 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
         uint4* dst = reinterpret_cast<uint4*>(lds);
         for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
         __syncthreads();
-        return view_of(lds);
+#if defined(BMO_SCALAR_SCENE)
+        return view_of((const BMO_AS char*)P.blob);  // not instantiated at run time in this build (use_lds is forced off)
+#else
+        return view_of((const char*)lds);
+#endif
     } else {
-        return view_of(P.blob);
+        return view_of((const BMO_AS char*)P.blob);
     }
 }
 
@@ -866,7 +871,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     lap("setup");
     const uint32_t blob_bytes = (uint32_t)scene->blob.size();
+#if defined(BMO_SCALAR_SCENE)
+    const int use_lds = 0;  // scene tables are read with scalar loads through the constant address space
+#else
     const int use_lds = (blob_bytes <= 120 * 1024 && !getenv("BMO_NO_LDS")) ? 1 : 0;
+#endif
     DBG("roots initialised n=%lld blob=%u use_lds=%d", (long long)n, blob_bytes, use_lds);
     if (dbg_on()) {
         HIP_TRY(hipStreamSynchronize(stream));

@@ -40,14 +40,42 @@
 
 namespace bmo {
 
+// Scene tables can be addressed through the constant address space (scalar loads, operands in SGPRs) when the build
+// defines BMO_SCALAR_SCENE; otherwise they are plain (generic / LDS) pointers.
+#if defined(__HIPCC__) && defined(BMO_SCALAR_SCENE)
+#define BMO_AS __attribute__((address_space(4)))
+#else
+#define BMO_AS
+#endif
+// BMO_UNIFORM(i): an index that is the same in every active lane by construction (loop counters of loops whose trip count
+// comes from a wave-uniform table entry); tells the compiler so, which keeps the dependent table reads scalar.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
+#define BMO_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
+#else
+#define BMO_UNIFORM(i) (i)
+#endif
+typedef const BMO_AS bmo_shape CShape;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
+static __device__ __forceinline__ CShape* uniform_shape_ptr(CShape* p) {  // same contract as BMO_UNIFORM, for a table entry
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (CShape*)(((uint64_t)hi << 32) | lo);
+}
+#else
+static BMO_HD CShape* uniform_shape_ptr(CShape* p) { return p; }
+#endif
+typedef const BMO_AS bmo_object CObject;
+typedef const BMO_AS double CDouble;
+typedef const BMO_AS int32_t CInt;
+
 
 struct SceneView {
-    const bmo_object* objects;
-    const bmo_shape* shapes;
-    const int32_t* children;
-    const double* tris;
-    const double* n_table;
-    const double* coefs;
+    CObject* objects;
+    CShape* shapes;
+    CInt* children;
+    CDouble* tris;
+    CDouble* n_table;
+    CDouble* coefs;
     int32_t n_objects, n_lambda;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int32_t march_iters;
@@ -169,9 +197,9 @@ BMO_HD bool isapprox(double x, double y, double atol) {
 // ------------------------------------------------------------------ SDF evaluation
 // _world_to_sdf (AbstractSDF.jl:35-40): rows of the stored transposed orientation, left fold
 template <class T>
-BMO_HD v3<T> to_local(const bmo_shape& s, const v3<T>& pt) {
+BMO_HD v3<T> to_local(CShape& s, const v3<T>& pt) {
     T dx = pt.x - s.pos[0], dy = pt.y - s.pos[1], dz = pt.z - s.pos[2];
-    const double* m = s.tdir;
+    CDouble* m = s.tdir;
     return {(m[0] * dx + m[1] * dy) + m[2] * dz, (m[3] * dx + m[4] * dy) + m[5] * dz, (m[6] * dx + m[7] * dy) + m[8] * dz};
 }
 
@@ -236,7 +264,7 @@ BMO_HD double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }
 BMO_HD Dual clamp01(const Dual& x) { return x.v > 1.0 ? Dual{1.0, 0, 0, 0} : (x.v < 0.0 ? Dual{0.0, 0, 0, 0} : x); }
 // aspheric_equation :133-141 and the first component of gradient_aspheric_equation :147-156, one pass over the coefficients
 template <class T>
-BMO_HD void asph_eval(const T& r, double c, double k, const double* a, int na, T& z, T& g) {
+BMO_HD void asph_eval(const T& r, double c, double k, CDouble* a, int na, T& z, T& g) {
     const T r2 = lit2(r);
     const T sa1 = 1 - (1 + k) * (c * c) * r2;
     const double Ri = 1 / c;
@@ -270,7 +298,7 @@ BMO_HD T sd_line_segment(const T& px, const T& py, double ax, double ay, double 
 }
 // convex_/concave_aspheric_surface_distance :186-307
 template <class T>
-BMO_HD T asph_distance(bool convex, const T& r, const T& z, double c, double k, double d, const double* a, int na, double max_sag) {
+BMO_HD T asph_distance(bool convex, const T& r, const T& z, double c, double k, double d, CDouble* a, int na, double max_sag) {
     const T r2 = lit2(r);
     const double r2_bound = (d / 2) * (d / 2);
     T zv, g;
@@ -326,16 +354,16 @@ BMO_HD T asph_distance(bool convex, const T& r, const T& z, double c, double k, 
 }
 // aspheres are never differentiated (normal3d = numeric_gradient, AsphericalLensSDF.jl:5): the Dual overload returns NaN,
 // which sends normal_any straight to the same central-difference stencil.
-BMO_HD double asph_leaf(const bmo_shape& s, const double* coefs, double r, double y) {
+BMO_HD double asph_leaf(CShape& s, CDouble* coefs, double r, double y) {
     return asph_distance<double>(s.kind == BMO_SHAPE_ASPH_CONVEX, r, y, 1 / s.p[0], s.p[1], s.p[2], coefs + s.child_begin, s.child_count, s.p[3]);
 }
-BMO_HD Dual asph_leaf(const bmo_shape&, const double*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
+BMO_HD Dual asph_leaf(CShape&, CDouble*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
 
 // leaf SDFs; `pt` is in the parent's frame (world, or the meniscus frame)
 // ASPH ("extended shapes"): compile the aspheric and cylinder-lens branches in.  Scenes without them run kernels
 // instantiated with ASPH = false (half the code, fewer registers).
 template <class T, bool ASPH>
-BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt, const double* coefs) {
+BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
     v3<T> p = to_local(s, pt);
     const int kind = s.kind;
     if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
@@ -443,7 +471,7 @@ BMO_HD T sdf_leaf(const bmo_shape& s, const v3<T>& pt, const double* coefs) {
 
 // leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
 template <class T, bool ASPH>
-BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
+BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
     const bool men = s.kind == BMO_SHAPE_MENISCUS;
     v3<T> p = pt;
     if (men) p = to_local(s, pt);
@@ -451,7 +479,7 @@ BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
     T a = T{}, b = T{}, c = T{};
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
-        const bmo_shape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
+        CShape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
         T v = sdf_leaf<T, ASPH>(leaf, p, S.coefs);
         if (q == 0) a = v;
         else if (q == 1) b = v;
@@ -464,7 +492,7 @@ BMO_HD T sdf_simple(const SceneView& S, const bmo_shape& s, const v3<T>& pt) {
 // sdf(shape, p) for any SDF shape incl. UnionSDF (UnionSDF.jl:53-56, left-fold min) together with
 // the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
 template <bool ASPH>
-BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t& best_child) {
+BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child) {
     const v3<double> pt{p.x, p.y, p.z};
     const bool uni = s.kind == BMO_SHAPE_UNION;
     const int nch = uni ? s.child_count : 1;
@@ -472,21 +500,24 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
     best_child = 0;
     BMO_NOUNROLL
     for (int c = 0; c < nch; ++c) {
-        const bmo_shape& ch = uni ? S.shapes[S.children[s.child_begin + c]] : s;
+        CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[S.children[s.child_begin + BMO_UNIFORM(c)]] : &s);
+        bool skip = false;
         if (c > 0 && ch.bs_radius >= 0.0 && !(ch.flags & BMO_SHAPE_FLAG_INEXACT)) {
             // Child skip (result-preserving): outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6.
             // If p is outside that sphere by more than max(best, 0), the child's value is > best, so it can change neither
             // the left-fold min (UnionSDF.jl:53-56) nor the first-minimum index (UnionSDF.jl:86-91).
             const double ox = p.x - ch.bs_center[0], oy = p.y - ch.bs_center[1], oz = p.z - ch.bs_center[2];
             const double lim = ch.bs_radius + (best > 0.0 ? best : 0.0);
-            if ((ox * ox + oy * oy) + oz * oz > lim * lim) continue;
+            skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
         }
-        double v = sdf_simple<double, ASPH>(S, ch, pt);
-        if (c == 0) {
-            best = v;
-        } else {
-            if ((v < best) || (v == best && sgn(v) && !sgn(best))) best_child = c;
-            best = jmin(best, v);
+        if (!skip) {
+            double v = sdf_simple<double, ASPH>(S, ch, pt);
+            if (c == 0) {
+                best = v;
+            } else {
+                if ((v < best) || (v == best && sgn(v) && !sgn(best))) best_child = c;
+                best = jmin(best, v);
+            }
         }
     }
     return best;
@@ -495,8 +526,8 @@ BMO_HD double sdf_any(const SceneView& S, const bmo_shape& s, const d3& p, int32
 // normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88)
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_t best_child) {
-    const bmo_shape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
+BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child) {
+    CShape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
     v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
     Dual y = sdf_simple<Dual, ASPH>(S, sh, x);
     d3 n = normalize_inv(d3{y.a, y.b, y.c});
@@ -524,7 +555,7 @@ BMO_HD d3 normal_any(const SceneView& S, const bmo_shape& s, const d3& p, int32_
 // Returns < 0 when the reference provably returns `nothing` for this shape and ray (the line misses the
 // inflated bounding sphere, or the origin is outside it and receding); otherwise a lower bound (>= 0) of the
 // ray parameter t of any hit: the hit point lies inside the sphere, so t >= the sphere entry parameter.
-BMO_HD double cull_entry(const bmo_shape& s, const d3& pos, const d3& dir) {
+BMO_HD double cull_entry(CShape& s, const d3& pos, const d3& dir) {
     double R = s.bs_radius;
     if (!(R >= 0.0)) return 0.0;
     d3 oc{s.bs_center[0] - pos.x, s.bs_center[1] - pos.y, s.bs_center[2] - pos.z};
@@ -535,7 +566,7 @@ BMO_HD double cull_entry(const bmo_shape& s, const d3& pos, const d3& dir) {
     if (disc < 0.0) return -1.0;         // the whole line misses the sphere
     return (b - sqrt(disc)) / dd;
 }
-BMO_HD bool cull_receding(const bmo_shape& s, const d3& pos, const d3& dir) {
+BMO_HD bool cull_receding(CShape& s, const d3& pos, const d3& dir) {
     double R = s.bs_radius;
     if (!(R >= 0.0)) return false;
     d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
@@ -543,7 +574,7 @@ BMO_HD bool cull_receding(const bmo_shape& s, const d3& pos, const d3& dir) {
 }
 
 // MoellerTrumboreAlgorithm Mesh.jl:203-237
-BMO_HD double moeller_trumbore(const double* f, const d3& pos, const d3& dir, double keps, double leps) {
+BMO_HD double moeller_trumbore(CDouble* f, const d3& pos, const d3& dir, double keps, double leps) {
     d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
     d3 E1 = sub3(V2, V1), E2 = sub3(V3, V1);
     d3 Pv = cross3(dir, E2);
@@ -576,7 +607,7 @@ BMO_HD double moeller_trumbore(const double* f, const d3& pos, const d3& dir, do
 //   pruned shape is provably a loser; results are unchanged (DESIGN.md "nearest-hit prune").
 template <bool ASPH>
 BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit) {
-    const bmo_shape& s = S.shapes[sid];
+    CShape& s = S.shapes[sid];
     Hit h = no_hit();
     {
         const double t_lb = cull_entry(s, pos0, dir0);
@@ -595,7 +626,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
             }
         }
         if (fid < 0) return h;
-        const double* f = S.tris + 9 * (s.tri_begin + fid);
+        CDouble* f = S.tris + 9 * (s.tri_begin + fid);
         d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
         d3 n = normalize_div(cross3(sub3(V2, V1), sub3(V3, V1)));  // normal3d(mesh, fID) Mesh.jl:183-192
         h.t = t0;
@@ -687,11 +718,12 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
     const int first = hint_shape >= 0 ? -1 : 0;
     if (hint_shape >= 0) calls += 1;
     BMO_NOUNROLL
-    for (int o = first; o < S.n_objects; ++o) {
+    for (int o = -1; o < S.n_objects; ++o) {  // the induction variable stays wave-uniform; un-hinted lanes skip slot -1
+        if (o < first) continue;
         int kind = BMO_OBJ_INTERSECTABLE, np = 1;
         int32_t sh0 = hint_shape, sh1 = -1, sh2 = -1;
         if (o >= 0) {
-            const bmo_object& ob = S.objects[o];
+            CObject& ob = S.objects[o];
             kind = ob.kind;
             sh0 = ob.shape[0];
             sh1 = ob.shape[1];
@@ -712,7 +744,22 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
             // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
             // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
             if (o >= 0 && sid == hint_shape) continue;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
+            // waterfall: the shape id is made wave-uniform (one pass per distinct id; only the hinted slot can differ
+            // between lanes), so every table read inside becomes a scalar load.
+            Hit tmp = no_hit();
+            for (bool pending = true; pending;) {
+                const int32_t u = __builtin_amdgcn_readfirstlane(sid);
+                int32_t u_cmp = u;
+                asm volatile("" : "+s"(u_cmp));  // keeps the optimiser from substituting the per-lane id back for `u`
+                if (u_cmp == sid) {
+                    tmp = intersect_shape<ASPH>(S, u, pos, dir, lim);
+                    pending = false;
+                }
+            }
+#else
             Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim);
+#endif
             if (tmp.shape < 0) continue;
             if (res.shape < 0) {
                 res = tmp;
@@ -878,7 +925,7 @@ BMO_HD d3 hit_point(const RayS& r, double t) { return axpy3(r.pos, t, r.dir); }
 template <int KIND>
 BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, double lambda, double opl_before, StepOut& o,
                      int ent_override = -1) {
-    const bmo_object& ob = S.objects[X.obj];
+    CObject& ob = S.objects[X.obj];
     o.outcome = OUT_STOP;
     o.hint_obj = o.hint_shape = -1;
     o.det_slot = -1;
@@ -1065,7 +1112,7 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
         return;
     }
     if (action == A_SPOT) {
-        const bmo_shape& m = S.shapes[ob.shape[0]];
+        CShape& m = S.shapes[ob.shape[0]];
         d3 loc{hp.x - m.pos[0], hp.y - m.pos[1], hp.z - m.pos[2]};
         o.det[0] = dot3(loc, d3{m.dir[0], m.dir[3], m.dir[6]});
         o.det[1] = dot3(loc, d3{m.dir[2], m.dir[5], m.dir[8]});
@@ -1085,8 +1132,8 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
         return;
     }
     if (action == A_POLARIZER) {  // JonesCalculus.jl:29-45: P = Q (R J R') Q, Q = I - d d'
-        const bmo_shape& m = S.shapes[ob.shape[0]];
-        const double* R = m.dir;
+        CShape& m = S.shapes[ob.shape[0]];
+        CDouble* R = m.dir;
         cx J[9], A[9], P[9], B[9], P2[9];
         for (int i = 0; i < 9; ++i) J[i] = {ob.jones[2 * i], ob.jones[2 * i + 1]};
         for (int i = 0; i < 3; ++i)
@@ -1238,7 +1285,7 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
         return;
     }
     const int32_t oid = o.Xc.obj;
-    const bmo_object& ob = S.objects[oid];
+    CObject& ob = S.objects[oid];
     const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && o.Xc.shape == ob.shape[1]) ||
                          (ob.kind == BMO_OBJ_CUBE_BS && o.Xc.shape == ob.shape[2]);
     // every sub-beam interacts with the object found by the CHIEF ray (System.jl:306-309, Gaussian.jl:124-135)
