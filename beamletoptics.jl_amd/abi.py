@@ -147,6 +147,8 @@ def load_engine():
     lib.bmo_result_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.bmo_result_view.argtypes = [vp, C.POINTER(ResultView)]
     lib.bmo_result_free.argtypes = [vp]
+    dp = C.POINTER(C.c_double)
+    lib.bmo_psf_intensity.argtypes = [C.c_void_p, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp, dp]
     _engine = lib
     return lib
 
@@ -155,3 +157,31 @@ def check(lib, rc, what):
     if rc != 0:
         msg = lib.bmo_last_error()
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def psf_intensity(hits, origin, e1, e2, xs, zs, device=0, hits_device_ptr=None, n_hits=None, want_field=False):
+    """bmo_psf_intensity: returns (I[n, n] indexed [i, j], field or None, kernel_ms).  `hits` is a host [H, 9] array, or pass
+    `hits_device_ptr` + `n_hits` for a buffer already resident on `device` (bmo_result_device_hits)."""
+    lib = load_engine()
+    dp = C.POINTER(C.c_double)
+
+    def arr(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(dp)
+
+    (o, op), (a1, e1p), (a2, e2p), (x, xp), (z, zp) = arr(origin), arr(e1), arr(e2), arr(xs), arr(zs)
+    n = len(x)
+    if len(z) != n:
+        raise ValueError("xs and zs must have the same length")
+    if hits_device_ptr is None:
+        h = np.ascontiguousarray(np.asarray(hits, dtype=np.float64).reshape(-1, 9))
+        hp, nh, on_dev = h.ctypes.data_as(C.c_void_p), len(h), 0
+    else:
+        hp, nh, on_dev = C.c_void_p(int(hits_device_ptr)), int(n_hits), 1
+    out = np.zeros(n * n)
+    fld = np.zeros(2 * n * n) if want_field else None
+    ms = C.c_double()
+    check(lib, lib.bmo_psf_intensity(hp, nh, on_dev, op, e1p, e2p, xp, zp, n, int(device), out.ctypes.data_as(dp),
+                                     fld.ctypes.data_as(dp) if want_field else None, C.byref(ms)), "bmo_psf_intensity")
+    field = (fld[0::2] + 1j * fld[1::2]).reshape(n, n).T.copy() if want_field else None
+    return out.reshape(n, n).T.copy(), field, ms.value

@@ -358,6 +358,43 @@ class PSFDetector(AbstractObject):  # Detectors/PSFDetector.jl:44-68
     def empty(self):
         self.data = np.zeros((0, 9))
 
+    # ---- read-out (PSFDetector.jl:91-237); the n x n coherent sum runs on the GPU engine (bmo_psf_intensity)
+    def calc_local_pos(self):  # PSFDetector.jl:91-101
+        loc = self.data[:, 0:3] - self.position()[None, :]
+        o = self.orientation()
+        return np.stack([loc @ o[:, 0], loc @ o[:, 2]], axis=1)
+
+    def calc_local_lims(self, crop_factor=1.0, center="centroid"):  # PSFDetector.jl:116-144
+        hits = self.calc_local_pos()
+        xs, zs = hits[:, 0], hits[:, 1]
+        if center == "centroid":
+            w = self.data[:, 7]
+            w_sum = w.sum()
+            x0, z0 = (w * xs).sum() / w_sum, (w * zs).sum() / w_sum
+        else:
+            x0, z0 = (xs.min() + xs.max()) / 2, (zs.min() + zs.max()) / 2
+        hwx, hwy = np.abs(xs - x0).max() * crop_factor, np.abs(zs - z0).max() * crop_factor
+        return x0 - hwx, x0 + hwx, z0 - hwy, z0 + hwy
+
+    def sample_axes(self, n=100, crop_factor=1.0, center="centroid", x_min=math.inf, x_max=math.inf, z_min=math.inf, z_max=math.inf,
+                    x0_shift=0.0, z0_shift=0.0):
+        """The (xs, zs) sample coordinates of intensity(psf; ...) PSFDetector.jl:205-217."""
+        _x_min, _x_max, _z_min, _z_max = self.calc_local_lims(crop_factor=crop_factor, center=center)
+        if x_min != math.inf and x_max != math.inf:
+            _x_min, _x_max = x_min, x_max
+        if z_min != math.inf and z_max != math.inf:
+            _z_min, _z_max = z_min, z_max
+        return la.linrange(_x_min, _x_max, n) + x0_shift, la.linrange(_z_min, _z_max, n) + z0_shift
+
+    def intensity(self, n=100, device=0, _intensity_fn=None, **kw):
+        """intensity(psf; n, crop_factor, center, x_min, ...) -> (xs, zs, I) with I[i, j] (PSFDetector.jl:190-237)."""
+        from . import abi
+
+        xs, zs = self.sample_axes(n=n, **kw)
+        o = self.orientation()
+        fn = _intensity_fn or (lambda *a: abi.psf_intensity(*a, device=device)[0])
+        return xs, zs, fn(self.data, self.position(), o[:, 0], o[:, 2], xs, zs)
+
 
 class IntersectableObject(AbstractObject):  # Intersectable.jl:10-15
     kind = O_INTERSECTABLE

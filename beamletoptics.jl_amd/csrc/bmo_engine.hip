@@ -1313,3 +1313,5 @@ int bmo_result_free(bmo_trace_result* r) {
 }
 
 }  // extern "C"
+
+#include "bmo_readout.inc.hpp"

@@ -86,3 +86,11 @@ def check_sag(r, d):
     """OpticUtils.jl:155-161."""
     if abs(2 * r) < d:
         raise ValueError(f"Radius of curvature (r = {r}) must be >= than half the diameter (d = {d}) or an illegal shape results!")
+
+
+def linrange(start, stop, n):
+    """LinRange(start, stop, n) as Julia evaluates its elements: lerpi(j, d, a, b) = (1 - t)*a + t*b with t = j/d, d = max(n - 1, 1)
+    (Base range.jl `lerpi`; part of Julia Base, which is not under /root/reference — see DESIGN.md "unpinned arithmetic")."""
+    d = max(int(n) - 1, 1)
+    t = np.arange(int(n), dtype=np.float64) / d
+    return (1 - t) * float(start) + t * float(stop)

@@ -275,6 +275,24 @@ int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* tot
 int bmo_result_view(bmo_trace_result* res, bmo_trace_result_view* view);
 int bmo_result_free(bmo_trace_result* res);
 
+/* ------------------------------------------------------------------------------------------------
+ * Detector read-out: intensity(psf::PSFDetector) — src/OpticalComponents/Detectors/PSFDetector.jl:190-237.
+ *
+ *   field(i,j) = sum over hits h of  proj_h * cis(k_h * (opl_h + dot(p_ij - hit_h, dir_h))),   p_ij = origin + xs[i]*e1 + zs[j]*e2
+ *   intensity  = abs2(field)                       (raw / unscaled, as the reference returns it)
+ *
+ * hits    : [n_hits][9] doubles (hit xyz, dir xyz, opl, proj, k) — the PSF rows of bmo_trace_result_view::det_data or the
+ *           device pointer of bmo_result_device_hits (hits_on_device != 0: pointer on `device`).
+ * xs, zs  : the n sample coordinates of the detector-local x and z axes (host arrays; the reference's LinRange + shift).
+ * out_intensity : host, n*n doubles, element (i,j) at [i + n*j]  (Julia's column-major Matrix).
+ * out_field     : optional host buffer, n*n complex values as (re, im) pairs, same order; may be NULL.
+ * kernel_ms     : optional; HIP-event time of the accumulation kernels.
+ * The sum over hits is evaluated in a fixed blocked order (deterministic, but not the reference's sequential order):
+ * parity with the reference is to the floating-point tolerance of a re-associated sum, not bit-exact.            */
+int bmo_psf_intensity(const double* hits, int64_t n_hits, int32_t hits_on_device, const double origin[3], const double e1[3],
+                      const double e2[3], const double* xs, const double* zs, int32_t n, int32_t device, double* out_intensity,
+                      double* out_field, double* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

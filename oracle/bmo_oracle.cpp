@@ -1607,4 +1607,31 @@ void bmo_cpu_global_E0(const double* in_dir, const double* out_dir, const double
     }
 }
 
+// intensity(psf::PSFDetector) PSFDetector.jl:190-237 — the coherent sum over recorded hits, evaluated per grid point in
+// the order the hits were pushed (the reference's `for h in psf.data`; its @simd annotation permits re-association, the
+// sequential order is the canonical one).  hits = [n_hits][9] (hit, dir, opl, proj, k); out (i,j) at [i + n*j].
+void bmo_cpu_psf_intensity(const double* hits, long long n_hits, const double* origin, const double* e1, const double* e2, const double* xs,
+                           const double* zs, int n, double* out_intensity, double* out_field) {
+    for (int j = 0; j < n; ++j) {           // Threads.@threads for j in eachindex(zs)
+        const double z = zs[j];
+        for (int i = 0; i < n; ++i) {
+            const double x = xs[i];
+            const D3 p{(origin[0] + x * e1[0]) + z * e2[0], (origin[1] + x * e1[1]) + z * e2[1], (origin[2] + x * e1[2]) + z * e2[2]};
+            double re = 0.0, im = 0.0;
+            for (long long h = 0; h < n_hits; ++h) {
+                const double* r = hits + 9 * h;
+                const double l = ((p.x - r[0]) * r[3] + (p.y - r[1]) * r[4]) + (p.z - r[2]) * r[5];   // dot(p - position(h), direction(h))
+                const double ph = r[8] * (r[6] + l);                                                // wavenumber * (opl + l)
+                re += r[7] * std::cos(ph);                                                         // projection_factor * cis(...)
+                im += r[7] * std::sin(ph);
+            }
+            out_intensity[i + (size_t)n * j] = re * re + im * im;  // abs2
+            if (out_field) {
+                out_field[2 * (i + (size_t)n * j)] = re;
+                out_field[2 * (i + (size_t)n * j) + 1] = im;
+            }
+        }
+    }
+}
+
 }  // extern "C"

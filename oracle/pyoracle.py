@@ -42,6 +42,8 @@ def lib():
         L.bmo_cpu_refraction3d.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
         L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
+        L.bmo_cpu_psf_intensity.argtypes = [dp, C.c_longlong, dp, dp, dp, dp, dp, C.c_int, dp, dp]
+        L.bmo_cpu_psf_intensity.restype = None
         _lib = L
     return _lib
 
@@ -133,3 +135,16 @@ def fresnel_coefficients(theta, n):
     o, po = _d(np.zeros(8))
     lib().bmo_cpu_fresnel(theta, n, po)
     return complex(o[0], o[1]), complex(o[2], o[3]), complex(o[4], o[5]), complex(o[6], o[7])
+
+
+def psf_intensity(hits, origin, e1, e2, xs, zs):
+    """intensity(psf) on the CPU, hits in push order; returns (I[n, n], field[n, n]) indexed [i, j] like the reference's Matrix."""
+    L = lib()
+    hits, hp = _d(np.asarray(hits, dtype=np.float64).reshape(-1, 9))
+    n = len(xs)
+    (_, op), (_, e1p), (_, e2p), (_, xp), (_, zp) = _o, _a, _b, _x, _z = _d(origin), _d(e1), _d(e2), _d(xs), _d(zs)
+    I = np.zeros(n * n)
+    F = np.zeros(2 * n * n)
+    L.bmo_cpu_psf_intensity(hp, len(hits), op, e1p, e2p, xp, zp, n, I.ctypes.data_as(C.POINTER(C.c_double)), F.ctypes.data_as(C.POINTER(C.c_double)))
+    field = (F[0::2] + 1j * F[1::2]).reshape(n, n).T  # stored [i + n*j] -> [j, i]; transpose to [i, j]
+    return I.reshape(n, n).T.copy(), field.copy()
