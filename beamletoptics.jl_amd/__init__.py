@@ -10,5 +10,5 @@ from .linalg import inch, rotate3d as rotation_matrix, align3d as alignment_matr
 from .shapes import *  # noqa: F401,F403
 from .components import *  # noqa: F401,F403
 from .beams import *  # noqa: F401,F403
-from .system import System, StaticSystem, CompiledScene, Engine, solve_system, make_batch  # noqa: F401
+from .system import System, StaticSystem, CompiledScene, Engine, solve_system, make_batch, release, EngineSolution  # noqa: F401
 from . import abi, linalg, shapes, components, beams, system  # noqa: F401

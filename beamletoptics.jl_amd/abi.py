@@ -104,6 +104,22 @@ class TraceResult:
         self.det_node = _np(v.det_node, tot, np.int32)
         self.det_data = _np(v.det_data, tot * 9, np.float64).reshape(tot, 9)
 
+    def as_view(self):
+        """A ResultView over this object's numpy arrays (valid while `self` is alive) — e.g. the `prev` of a test emulator."""
+        v = ResultView()
+        v.n_roots, v.n_nodes, v.n_records, v.n_intersect_calls = self.n_roots, self.n_nodes, self.n_records, self.n_intersect_calls
+        v.n_steps, v.beam_kind, v.rec_planes, v.n_detectors = self.n_steps, self.beam_kind, self.rec_planes, self.n_detectors
+        keep = []
+        for name, ct in (("node_root", C.c_int32), ("node_parent", C.c_int32), ("node_first_child", C.c_int32), ("node_first_rec", C.c_int32),
+                         ("node_nseg", C.c_int32), ("node_status", C.c_int32), ("node_aux", C.c_double), ("rec_obj", C.c_int32),
+                         ("rec_shape", C.c_int32), ("rec", C.c_double), ("det_count", C.c_int64), ("det_offset", C.c_int64),
+                         ("det_node", C.c_int32), ("det_data", C.c_double)):
+            a = np.ascontiguousarray(getattr(self, name))
+            keep.append(a)
+            setattr(v, name, a.ctypes.data_as(C.POINTER(ct)))
+        self._view_keep = keep
+        return v
+
     def detector_hits(self, slot):
         o, c = int(self.det_offset[slot]), int(self.det_count[slot])
         return self.det_data[o:o + c]
@@ -147,6 +163,8 @@ def load_engine():
     lib.bmo_result_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.bmo_result_view.argtypes = [vp, C.POINTER(ResultView)]
     lib.bmo_result_free.argtypes = [vp]
+    lib.bmo_retrace.argtypes = [vp, C.POINTER(RayBatch), vp, C.POINTER(TraceOpts), C.POINTER(vp)]
+    lib.bmo_retrace_device.argtypes = [vp, vp, vp, C.POINTER(TraceOpts), C.POINTER(vp)]
     dp = C.POINTER(C.c_double)
     lib.bmo_psf_intensity.argtypes = [C.c_void_p, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp, dp]
     _engine = lib

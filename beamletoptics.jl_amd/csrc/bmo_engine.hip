@@ -144,6 +144,17 @@ struct NodeArrays {
     double* aux;  // [cap][4]: Gaussian l0 (length of parent chief), w0, Re(E0), Im(E0)
     int64_t cap;
     int32_t hit_sub;  // detector records per node: 1 (Ray / PolarizedRay), 3 (GaussianBeamlet: chief, waist, divergence)
+    int32_t* old;     // retrace only: node of the previous solution this beam re-walks, -1 once it traces freshly
+};
+
+// Tables of the previous solution a retrace re-walks (System.jl:188-255), indexed by ITS node ids; all device pointers.
+struct OldSolution {
+    const int32_t* nseg;         // stored rays per beam
+    const int32_t* status;       // BMO_NODE_SPLIT <=> the beam has (two) children
+    const int32_t* first_child;  // node id of the transmitted child; the reflected one follows
+    const int32_t* rec_start;    // exclusive scan of nseg
+    const int32_t* rec_obj;      // [rec_start[node] + k]: object of the stored intersection of ray k, -1 = none
+    const double* aux;           // Gaussian: [node][4] = l0, w0, Re E0, Im E0
 };
 
 struct StepParams {
@@ -155,7 +166,26 @@ struct StepParams {
     unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
     NodeArrays nodes;
     int32_t r_max;
+    OldSolution old;  // RETR kernels only
 };
+
+// Per-lane retrace context (shared by the Beam and the GaussianBeamlet step kernels; tests/emu walks the same rules)
+struct RetraceLane {
+    int32_t old = -1, old_n = 0, probe_obj = -1;
+    bool probe = false, fresh_allowed = true, missed = false;
+};
+__device__ __forceinline__ RetraceLane retrace_lane(const StepParams& P, int32_t node, int32_t k) {
+    RetraceLane r;
+    r.old = P.nodes.old[node];
+    if (r.old >= 0) {
+        r.old_n = P.old.nseg[r.old];
+        r.probe_obj = P.old.rec_obj[(int64_t)P.old.rec_start[r.old] + k];
+        r.fresh_allowed = k + 1 < P.r_max;
+        r.probe = r.probe_obj >= 0;
+        r.missed = !r.probe;  // a stored ray without intersection: cleanup, trace_system! goes on without a hint
+    }
+    return r;
+}
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ inline int prefix_rank(unsigned long long mask) {
@@ -235,7 +265,7 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
     }
 }
 
-template <int KIND, bool LDS, bool ASPH>
+template <int KIND, bool LDS, bool ASPH, bool RETR>
 __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
@@ -254,6 +284,8 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
     o.det_slot = -1;
     uint32_t calls = 0;
     double opl_next = 0.0, lambda = 0.0;
+    RetraceLane rt;
+    bool still = false, old_kids = false;
 
     if (valid) {
         const double* D = P.cur.d;
@@ -276,12 +308,17 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
         X.t = kinf();
         X.n = {0, 0, 0};
         int status = 0;
-        if (flags & F_DEAD) {
+        int32_t hobj = I[I_HOBJ * cap + j], hshape = I[I_HSHAPE * cap + j];
+        if (RETR) {
+            rt = retrace_lane(P, node, k);
+            if (rt.old >= 0 && !rt.probe) hobj = hshape = -1;
+        }
+        if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
         } else {
-            X = tracing_step<ASPH>(S, ray.pos, ray.dir, I[I_HOBJ * cap + j], I[I_HSHAPE * cap + j], calls);
+            X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hobj, hshape, calls, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             if (X.shape < 0) {
-                status = BMO_NODE_MISS;
+                status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
             } else {
                 interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
                 status = o.status;
@@ -305,6 +342,12 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
         Dw[10 * cap + j] = X.n.z;
         I[I_OBJ * cap + j] = X.obj;
         I[I_SHAPE * cap + j] = X.shape;
+        if (RETR) {
+            still = rt.old >= 0 && rt.probe && !rt.missed;  // the stored path held at this ray
+            old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
+            if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+            if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
+        }
         if (!survive) {  // node ends here
             P.nodes.nseg[node] = k + 1;
             P.nodes.status[node] = status;
@@ -346,8 +389,13 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
     };
     if (survive) {
         const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
-        const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
-        write_next(slot, o.next, node, k + 1, o.hint_obj, o.hint_shape, fl, opl_next);
+        int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+        int32_t ho = o.hint_obj, hs = o.hint_shape;
+        if (RETR && still) {
+            if (k + 1 < rt.old_n) fl = 0;  // replace!: the next stored ray is re-walked whatever r_max says
+            else ho = hs = -1;            // push!, then trace_system! starts over without a hint
+        }
+        write_next(slot, o.next, node, k + 1, ho, hs, fl, opl_next);
     }
     if (split) {
         const int r = prefix_rank(al.m_split);
@@ -366,8 +414,9 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
                 P.nodes.lambda[c] = lambda;
                 P.nodes.hit_det[c] = -1;
                 P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
             }
-            const int32_t fl = (1 < P.r_max) ? 0 : F_DEAD;
+            const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
             write_next(slot, o.next, (int32_t)cn, 0, -1, -1, fl, opl_next);
             write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, fl, opl_next);
         } else {
@@ -378,7 +427,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
 
 
 // ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
-template <bool LDS, bool ASPH>
+template <bool LDS, bool ASPH, bool RETR>
 __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
@@ -392,6 +441,8 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
     GaussOut o;
     o.outcome = OUT_MISS;
     uint32_t calls = 0;
+    RetraceLane rt;
+    bool still = false, old_kids = false;
     if (valid) {
         double* D = P.cur.d;
         int32_t* I = P.cur.i;
@@ -420,10 +471,14 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         g.E0 = {P.nodes.aux[(int64_t)node * 4 + 2], P.nodes.aux[(int64_t)node * 4 + 3]};
         int status = 0;
         o.Xc = o.Xw = o.Xd = no_hit();
-        if (flags & F_DEAD) {
+        if (RETR) {
+            rt = retrace_lane(P, node, k);
+            if (rt.old >= 0 && !rt.probe) g.hint_obj = g.hint_shape = -1;
+        }
+        if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;
         } else {
-            gauss_step<ASPH>(S, g, o, calls);
+            gauss_step<ASPH, RETR>(S, g, o, calls, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
             else if (o.outcome == OUT_SPLIT) {
@@ -442,6 +497,12 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         st(22, o.Xd);
         I[I_OBJ * cap + j] = o.Xc.obj;
         I[I_SHAPE * cap + j] = o.Xc.shape;
+        if (RETR) {
+            still = rt.old >= 0 && rt.probe && !rt.missed;
+            old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
+            if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+            if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
+        }
         if (!survive) {
             P.nodes.nseg[node] = k + 1;
             P.nodes.status[node] = status;
@@ -486,8 +547,13 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
     };
     if (survive) {
         const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
-        const int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
-        write_next(slot, o.nc, o.nw, o.nd, node, k + 1, o.hint_obj, o.hint_shape, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+        int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+        int32_t ho = o.hint_obj, hs = o.hint_shape;
+        if (RETR && still) {
+            if (k + 1 < rt.old_n) fl = 0;
+            else ho = hs = -1;
+        }
+        write_next(slot, o.nc, o.nw, o.nd, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
     }
     if (split) {
         const int r = prefix_rank(al.m_split);
@@ -510,8 +576,13 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
                 P.nodes.aux[c * 4 + 1] = o.child_w0;
                 P.nodes.aux[c * 4 + 2] = w == 0 ? o.Et.re : o.Er.re;
                 P.nodes.aux[c * 4 + 3] = w == 0 ? o.Et.im : o.Er.im;
+                if (RETR) {
+                    const int32_t oc = old_kids ? P.old.first_child[rt.old] + w : -1;
+                    P.nodes.old[c] = oc;
+                    if (oc >= 0) P.nodes.aux[c * 4 + 1] = P.old.aux[(int64_t)oc * 4 + 1];  // _modify_beam_head! keeps the stored w0 (Gaussian.jl:154-161)
+                }
             }
-            const int32_t fl = (1 < P.r_max) ? 0 : F_DEAD;
+            const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
             // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
             write_next(slot, o.nc, o.nw, o.nd, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
             write_next(slot + 1, o.rc, o.rw, o.rd, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
@@ -563,6 +634,19 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
     nodes.key[j] = ((unsigned long long)j) << 32;
 }
 
+// retrace tables of a finished solution
+__global__ void old_obj_scatter_kernel(Chunk c, const int32_t* __restrict__ rec_start, int32_t* __restrict__ rec_obj) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c.count) return;
+    const int32_t node = c.i[I_NODE * c.cap + j], k = c.i[I_K * c.cap + j];
+    rec_obj[(int64_t)rec_start[node] + k] = c.i[I_OBJ * c.cap + j];
+}
+__global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key, int64_t n, int32_t* __restrict__ first_child) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int32_t p = parent[c];
+    if (p >= 0 && !(key[c] & 1ull)) first_child[p] = (int32_t)c;  // transmitted child (path bit 0); the reflected one is c + 1
+}
 __global__ void iota_kernel(int32_t* a, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) a[j] = (int32_t)j;
@@ -701,7 +785,7 @@ struct bmo_device_batch {
 };
 
 struct bmo_trace_result {
-    int device = 0, kind = 0, n_detectors = 0;
+    int device = 0, kind = 0, n_detectors = 0, n_objects = 0;
     int64_t n_roots = 0, n_nodes = 0, n_records = 0;
     unsigned long long calls = 0;
     int n_steps = 0;
@@ -712,6 +796,11 @@ struct bmo_trace_result {
     std::vector<std::unique_ptr<DevBuf>> arena;  // chunk storage
     std::vector<Chunk> chunks;
     DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, n_aux, order, det_data, det_node;
+    DevBuf n_old;  // retrace runs only (NodeArrays::old)
+    // tables a later bmo_retrace of THIS solution needs, built on first use (OldSolution)
+    std::mutex rt_mu;
+    bool rt_built = false;
+    DevBuf rt_rec_start, rt_rec_obj, rt_first_child;
     std::vector<int64_t> det_count, det_offset;
     // host views (filled by bmo_result_view)
     bool viewed = false;
@@ -721,10 +810,57 @@ struct bmo_trace_result {
 
 namespace {
 
+// OldSolution tables of `prev` (device arrays keyed by prev's node ids), built once per solution.
+int build_retrace_tables(bmo_trace_result* prev, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(prev->rt_mu);
+    if (prev->rt_built) return BMO_OK;
+    const int64_t nn = prev->n_nodes, nr = prev->n_records;
+    if (nr >= (int64_t)1 << 31) return fail(BMO_ERR_UNSUPPORTED, "retrace: previous solution has more than 2^31 segments");
+    int rc;
+    if ((rc = prev->rt_rec_start.alloc((size_t)std::max<int64_t>(nn, 1) * 4)) || (rc = prev->rt_rec_obj.alloc((size_t)std::max<int64_t>(nr, 1) * 4)) ||
+        (rc = prev->rt_first_child.alloc((size_t)std::max<int64_t>(nn, 1) * 4)))
+        return rc;
+    if (nn > 0) {
+        DevBuf tmp;
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)prev->n_nseg.p, (int32_t*)prev->rt_rec_start.p, (int)nn, stream));
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (const int32_t*)prev->n_nseg.p, (int32_t*)prev->rt_rec_start.p, (int)nn, stream));
+        for (const Chunk& c : prev->chunks)
+            if (c.count > 0)
+                hipLaunchKernelGGL(old_obj_scatter_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)prev->rt_rec_start.p,
+                                   (int32_t*)prev->rt_rec_obj.p);
+        HIP_TRY(hipMemsetAsync(prev->rt_first_child.p, 0xFF, (size_t)nn * 4, stream));
+        hipLaunchKernelGGL(old_first_child_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, (const int32_t*)prev->n_parent.p,
+                           (const unsigned long long*)prev->n_key.p, nn, (int32_t*)prev->rt_first_child.p);
+        HIP_TRY(hipStreamSynchronize(stream));  // tmp goes back to the pool
+        HIP_TRY(hipGetLastError());
+        if (dbg_on()) {
+            const int q = (int)std::min<int64_t>(nn, 6), qr = (int)std::min<int64_t>(nr, 24);
+            std::vector<int32_t> a(q), b(q), c(q), d(qr);
+            (void)hipMemcpy(a.data(), prev->n_nseg.p, q * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(b.data(), prev->rt_rec_start.p, q * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(c.data(), prev->rt_first_child.p, q * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(d.data(), prev->rt_rec_obj.p, qr * 4, hipMemcpyDeviceToHost);
+            for (int i = 0; i < q; ++i) DBG("retrace table node %d: nseg %d rec_start %d first_child %d", i, a[i], b[i], c[i]);
+            std::string line;
+            for (int i = 0; i < qr; ++i) line += std::to_string(d[i]) + " ";
+            DBG("retrace table rec_obj: %s", line.c_str());
+        }
+    }
+    prev->rt_built = true;
+    return BMO_OK;
+}
+
 template <int KIND>
-int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result* R) {
+int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result* R, bmo_trace_result* prev = nullptr) {
     using L = Layout<KIND>;
     const int device = batch->device;
+    if (prev) {
+        if (prev->device != device) return fail(BMO_ERR_INVALID, "retrace: the previous solution lives on another device");
+        if (prev->kind != KIND || prev->n_roots != batch->n)
+            return fail(BMO_ERR_INVALID, "retrace: batch does not match the previous solution (root count / beam kind)");
+    }
     HIP_TRY(hipSetDevice(device));
     int rc = BMO_OK;
     const char* dblob = scene->device_blob(device, rc);
@@ -786,6 +922,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if ((r = R->n_lambda.alloc(cap * 8))) return r;
         if ((r = R->n_hit.alloc(cap * 72 * nsub))) return r;
         if ((r = R->n_aux.alloc(cap * 32))) return r;
+        if (prev && (r = R->n_old.alloc(cap * 4))) return r;
         return BMO_OK;
     };
     if ((rc = alloc_nodes(node_cap))) return rc;
@@ -803,6 +940,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         a.aux = (double*)R->n_aux.p;
         a.cap = node_cap;
         a.hit_sub = nsub;
+        a.old = (int32_t*)R->n_old.p;
         return a;
     };
     auto grow_nodes = [&](int64_t need) -> int {
@@ -823,6 +961,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if ((r = mv(R->n_root, 4)) || (r = mv(R->n_parent, 4)) || (r = mv(R->n_nseg, 4)) || (r = mv(R->n_status, 4)) || (r = mv(R->n_li, 4)) ||
             (r = mv(R->n_hitdet, 4)) || (r = mv(R->n_key, 8)) || (r = mv(R->n_lambda, 8)) || (r = mv(R->n_hit, 72 * (size_t)nsub)) || (r = mv(R->n_aux, 32)))
             return r;
+        if (prev && (r = mv(R->n_old, 4))) return r;
         node_cap = ncap;
         return BMO_OK;
     };
@@ -865,9 +1004,21 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     Chunk cur;
     if ((rc = new_chunk(n, cur))) return rc;
     cur.count = n;
+    OldSolution old_tab{};
+    if (prev) {
+        if ((rc = build_retrace_tables(prev, stream))) return rc;
+        old_tab.nseg = (const int32_t*)prev->n_nseg.p;
+        old_tab.status = (const int32_t*)prev->n_status.p;
+        old_tab.first_child = (const int32_t*)prev->rt_first_child.p;
+        old_tab.rec_start = (const int32_t*)prev->rt_rec_start.p;
+        old_tab.rec_obj = (const int32_t*)prev->rt_rec_obj.p;
+        old_tab.aux = (const double*)prev->n_aux.p;
+    }
     if (n > 0) {
+        // a retrace re-walks the stored first ray whatever r_max says (System.jl:197); root j re-walks old node j
         hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
-                           (const int32_t*)batch->li.p, n, cur, node_arrays(), opts->r_max);
+                           (const int32_t*)batch->li.p, n, cur, node_arrays(), prev ? 0x7fffffff : opts->r_max);
+        if (prev) hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int32_t*)R->n_old.p, n);
     }
     lap("setup");
     const uint32_t blob_bytes = (uint32_t)scene->blob.size();
@@ -886,11 +1037,19 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     void (*kern)(StepParams) = nullptr;
     const bool asph = scene->hdr.has_asphere != 0;
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
-        kern = use_lds ? (asph ? &step_kernel_gauss<true, true> : &step_kernel_gauss<true, false>)
-                       : (asph ? &step_kernel_gauss<false, true> : &step_kernel_gauss<false, false>);
+        if (prev)
+            kern = use_lds ? (asph ? &step_kernel_gauss<true, true, true> : &step_kernel_gauss<true, false, true>)
+                           : (asph ? &step_kernel_gauss<false, true, true> : &step_kernel_gauss<false, false, true>);
+        else
+            kern = use_lds ? (asph ? &step_kernel_gauss<true, true, false> : &step_kernel_gauss<true, false, false>)
+                           : (asph ? &step_kernel_gauss<false, true, false> : &step_kernel_gauss<false, false, false>);
     } else {
-        kern = use_lds ? (asph ? &step_kernel<KIND, true, true> : &step_kernel<KIND, true, false>)
-                       : (asph ? &step_kernel<KIND, false, true> : &step_kernel<KIND, false, false>);
+        if (prev)
+            kern = use_lds ? (asph ? &step_kernel<KIND, true, true, true> : &step_kernel<KIND, true, false, true>)
+                           : (asph ? &step_kernel<KIND, false, true, true> : &step_kernel<KIND, false, false, true>);
+        else
+            kern = use_lds ? (asph ? &step_kernel<KIND, true, true, false> : &step_kernel<KIND, true, false, false>)
+                           : (asph ? &step_kernel<KIND, false, true, false> : &step_kernel<KIND, false, false, false>);
     }
     if (lds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -913,6 +1072,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
         P.nodes = node_arrays();
         P.r_max = opts->r_max;
+        P.old = old_tab;
         DBG("step %d launching m=%lld", steps, (long long)m);
         HIP_TRY(hipEventRecord(ev_a, stream));
         hipLaunchKernelGGL(kern, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
@@ -1166,17 +1326,39 @@ int bmo_batch_free(bmo_device_batch* b) {
     return BMO_OK;
 }
 
-int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result** out) {
+static int trace_or_retrace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result* prev, bmo_trace_result** out) {
     if (!scene || !batch || !opts || !out) return fail(BMO_ERR_INVALID, "null argument");
+    if (prev && prev->n_objects != scene->hdr.n_objects)
+        return fail(BMO_ERR_INVALID, "retrace: the scene does not have the object numbering the previous solution was solved with");
     auto R = std::make_unique<bmo_trace_result>();
+    R->n_objects = scene->hdr.n_objects;
     int rc;
-    if (batch->kind == BMO_BEAM_RAY) rc = run_trace<BMO_BEAM_RAY>(scene, batch, opts, R.get());
-    else if (batch->kind == BMO_BEAM_POLARIZED) rc = run_trace<BMO_BEAM_POLARIZED>(scene, batch, opts, R.get());
-    else if (batch->kind == BMO_BEAM_GAUSSIAN) rc = run_trace<BMO_BEAM_GAUSSIAN>(scene, batch, opts, R.get());
+    if (batch->kind == BMO_BEAM_RAY) rc = run_trace<BMO_BEAM_RAY>(scene, batch, opts, R.get(), prev);
+    else if (batch->kind == BMO_BEAM_POLARIZED) rc = run_trace<BMO_BEAM_POLARIZED>(scene, batch, opts, R.get(), prev);
+    else if (batch->kind == BMO_BEAM_GAUSSIAN) rc = run_trace<BMO_BEAM_GAUSSIAN>(scene, batch, opts, R.get(), prev);
     else return fail(BMO_ERR_UNSUPPORTED, "beam kind not built yet");
     if (rc) return rc;
     *out = R.release();
     return BMO_OK;
+}
+
+int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* opts, bmo_trace_result** out) {
+    return trace_or_retrace(scene, batch, opts, nullptr, out);
+}
+
+int bmo_retrace_device(bmo_scene* scene, bmo_device_batch* batch, bmo_trace_result* prev, const bmo_trace_opts* opts, bmo_trace_result** out) {
+    if (!prev) return fail(BMO_ERR_INVALID, "retrace: no previous solution");
+    return trace_or_retrace(scene, batch, opts, prev, out);
+}
+
+int bmo_retrace(bmo_scene* scene, const bmo_ray_batch* in, bmo_trace_result* prev, const bmo_trace_opts* opts, bmo_trace_result** out) {
+    if (!scene || !in || !opts || !out || !prev) return fail(BMO_ERR_INVALID, "null argument");
+    bmo_device_batch* b = nullptr;
+    int rc = bmo_batch_upload(scene, in, prev->device, &b);  // the stored solution pins the device
+    if (rc) return rc;
+    rc = bmo_retrace_device(scene, b, prev, opts, out);
+    bmo_batch_free(b);
+    return rc;
 }
 
 int bmo_trace(bmo_scene* scene, const bmo_ray_batch* in, const bmo_trace_opts* opts, bmo_trace_result** out) {

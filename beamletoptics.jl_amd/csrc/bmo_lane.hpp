@@ -712,78 +712,114 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
 // one loop over "slots": slot -1 is the hinted SHAPE (if any), slots 0..M-1 are the leaf objects.
 // Object-level rules: SingleShape/MultiShape AbstractRay.jl:118-155, plate splitter
 // PlateBeamsplitter.jl:160-187, NonInteractable.jl:19.  `calls` counts the reference's intersect3d calls.
-template <bool ASPH>
-BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls) {
+//
+// RETR builds add the probe of retrace_system! (System.jl:208-218) as a first pass over the same slot loop (so the big
+// intersect_shape body keeps its single call site): with `probe` set, pass 0 tests only the hinted shape
+// (intersect3d(shape(_hint), ray)) or, without a hint, only the object of the stored intersection
+// (intersect3d(object(_intersection), ray)); a probe miss is the reference's cleanup path, after which solve_leaf!
+// traces the same ray on WITHOUT a hint (System.jl:130-133) if `fresh_allowed` (length(rays) < r_max).
+template <bool ASPH, bool RETR = false>
+BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls,
+                        bool probe = false, int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     Hit X = no_hit();
-    const int first = hint_shape >= 0 ? -1 : 0;
-    if (hint_shape >= 0) calls += 1;
+    bool done = false;
+    int32_t skip_obj = -1;            // object already tested by the probe with this very ray (pure function => same `nothing`)
+    int32_t tested_shape = -1;        // shape tested in slot -1 (or by the probe) with this very ray
     BMO_NOUNROLL
-    for (int o = -1; o < S.n_objects; ++o) {  // the induction variable stays wave-uniform; un-hinted lanes skip slot -1
-        if (o < first) continue;
-        int kind = BMO_OBJ_INTERSECTABLE, np = 1;
-        int32_t sh0 = hint_shape, sh1 = -1, sh2 = -1;
-        if (o >= 0) {
-            CObject& ob = S.objects[o];
-            kind = ob.kind;
-            sh0 = ob.shape[0];
-            sh1 = ob.shape[1];
-            sh2 = ob.shape[2];
-            np = (kind == BMO_OBJ_DOUBLET) ? 2 : (kind == BMO_OBJ_CUBE_BS ? 3 : (kind == BMO_OBJ_PLATE_BS ? 2 : 1));
-            if (kind == BMO_OBJ_NONINTERACTABLE) np = 0;
-            if (kind == BMO_OBJ_PLATE_BS) {  // coating first, then substrate
-                int32_t t = sh0;
-                sh0 = sh1;
-                sh1 = t;
+    for (int pass = (RETR && probe) ? 0 : 1; pass < 2 && !done; ++pass) {
+        int32_t hs = hint_shape;  // shape tested in slot -1 of this pass (-1: none)
+        int o_lo = 0, o_hi = S.n_objects;
+        bool fall_back = true;    // slot -1 missed: go on with the object slots (trace_one -> trace_all)
+        if (RETR && pass == 0) {
+            calls += 1;
+            if (hint_shape >= 0) {
+                o_hi = 0;
+                fall_back = false;
+            } else {
+                o_lo = probe_obj;
+                o_hi = probe_obj + 1;
             }
+        } else if (RETR && probe) {  // the probe missed
+            if (probe_missed) *probe_missed = true;
+            if (!fresh_allowed) break;
+            if (hint_shape < 0) skip_obj = probe_obj;
+            hs = -1;
+            calls += (uint32_t)S.n_objects;
+        } else {
+            calls += hs >= 0 ? 1u : (uint32_t)S.n_objects;
         }
-        Hit res = no_hit();
+        if (hs >= 0) tested_shape = hs;
         BMO_NOUNROLL
-        for (int k = 0; k < np; ++k) {
-            const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
-            const double lim = (o >= 0 && X.shape >= 0) ? X.t + 1e-6 * (1.0 + X.t) : kinf();
-            // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
-            // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
-            if (o >= 0 && sid == hint_shape) continue;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
-            // waterfall: the shape id is made wave-uniform (one pass per distinct id; only the hinted slot can differ
-            // between lanes), so every table read inside becomes a scalar load.
-            Hit tmp = no_hit();
-            for (bool pending = true; pending;) {
-                const int32_t u = __builtin_amdgcn_readfirstlane(sid);
-                int32_t u_cmp = u;
-                asm volatile("" : "+s"(u_cmp));  // keeps the optimiser from substituting the per-lane id back for `u`
-                if (u_cmp == sid) {
-                    tmp = intersect_shape<ASPH>(S, u, pos, dir, lim);
-                    pending = false;
+        for (int o = -1; o < o_hi; ++o) {  // the induction variable stays wave-uniform; lanes skip the slots they do not use
+            if (o < 0 ? hs < 0 : (o < o_lo || o == skip_obj)) continue;
+            int kind = BMO_OBJ_INTERSECTABLE, np = 1;
+            int32_t sh0 = hs, sh1 = -1, sh2 = -1;
+            if (o >= 0) {
+                CObject& ob = S.objects[o];
+                kind = ob.kind;
+                sh0 = ob.shape[0];
+                sh1 = ob.shape[1];
+                sh2 = ob.shape[2];
+                np = (kind == BMO_OBJ_DOUBLET) ? 2 : (kind == BMO_OBJ_CUBE_BS ? 3 : (kind == BMO_OBJ_PLATE_BS ? 2 : 1));
+                if (kind == BMO_OBJ_NONINTERACTABLE) np = 0;
+                if (kind == BMO_OBJ_PLATE_BS) {  // coating first, then substrate
+                    int32_t t = sh0;
+                    sh0 = sh1;
+                    sh1 = t;
                 }
             }
+            Hit res = no_hit();
+            BMO_NOUNROLL
+            for (int k = 0; k < np; ++k) {
+                const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
+                const double lim = (o >= 0 && X.shape >= 0) ? X.t + 1e-6 * (1.0 + X.t) : kinf();
+                // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
+                // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
+                if (o >= 0 && sid == tested_shape) continue;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
+                // waterfall: the shape id is made wave-uniform (one pass per distinct id; only the hinted slot can differ
+                // between lanes), so every table read inside becomes a scalar load.
+                Hit tmp = no_hit();
+                for (bool pending = true; pending;) {
+                    const int32_t u = __builtin_amdgcn_readfirstlane(sid);
+                    int32_t u_cmp = u;
+                    asm volatile("" : "+s"(u_cmp));  // keeps the optimiser from substituting the per-lane id back for `u`
+                    if (u_cmp == sid) {
+                        tmp = intersect_shape<ASPH>(S, u, pos, dir, lim);
+                        pending = false;
+                    }
+                }
 #else
-            Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim);
+                Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim);
 #endif
-            if (tmp.shape < 0) continue;
-            if (res.shape < 0) {
-                res = tmp;
+                if (tmp.shape < 0) continue;
+                if (res.shape < 0) {
+                    res = tmp;
+                    continue;
+                }
+                if (kind == BMO_OBJ_PLATE_BS) {
+                    // res = coating, tmp = substrate: coating wins ties (isapprox) and when strictly nearer
+                    if (!(isapprox(res.t, tmp.t, 0.0) || res.t < tmp.t)) res = tmp;
+                } else if (tmp.t < res.t) {
+                    res = tmp;
+                }
+            }
+            if (o < 0) {  // hinted shape
+                if (res.shape >= 0) {
+                    res.obj = hint_obj;
+                    X = res;
+                    done = true;
+                    break;
+                }
+                if (!fall_back) break;
+                calls += (uint32_t)S.n_objects;  // fall back to trace_all
                 continue;
             }
-            if (kind == BMO_OBJ_PLATE_BS) {
-                // res = coating, tmp = substrate: coating wins ties (isapprox) and when strictly nearer
-                if (!(isapprox(res.t, tmp.t, 0.0) || res.t < tmp.t)) res = tmp;
-            } else if (tmp.t < res.t) {
-                res = tmp;
-            }
+            if (res.shape < 0) continue;
+            res.obj = o;
+            if (X.shape < 0 || res.t < X.t) X = res;
         }
-        if (o < 0) {  // hinted shape
-            if (res.shape >= 0) {
-                res.obj = hint_obj;
-                return res;
-            }
-            calls += (uint32_t)S.n_objects;  // fall back to trace_all
-            continue;
-        }
-        if (first == 0 && o == 0) calls += (uint32_t)S.n_objects;
-        if (res.shape < 0) continue;
-        res.obj = o;
-        if (X.shape < 0 || res.t < X.t) X = res;
+        if (RETR && pass == 0 && X.shape >= 0) done = true;  // the stored path still holds
     }
     return X;
 }
@@ -1253,8 +1289,13 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
     return o;
 }
 
-template <bool ASPH>
-BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls) {
+// RETR builds: with `probe` the three stored rays are first re-intersected with the hinted shape or the stored object
+// (retrace_system! System.jl:360-375; all three are always evaluated), and the stored path holds only if all three still
+// hit the same shape (:377-392).  Otherwise the beamlet is cut here and trace_system! goes on from these rays without a
+// hint (System.jl:274-318) when `fresh_allowed`.
+template <bool ASPH, bool RETR = false>
+BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, bool probe = false, int32_t probe_obj = -1,
+                       bool fresh_allowed = true, bool* probe_missed = nullptr) {
     o.outcome = OUT_MISS;
     o.status = 0;
     o.hint_obj = o.hint_shape = -1;
@@ -1263,16 +1304,33 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
     o.Xc = o.Xw = o.Xd = no_hit();
     // chief, waist, divergence in that order; stop at the first ray without intersection (System.jl:283-296)
     bool all_hit = true;
+    int32_t hint_obj = g.hint_obj, hint_shape = g.hint_shape;
     BMO_NOUNROLL
-    for (int r = 0; r < 3; ++r) {
-        const RayS ray = pick_ray(r, g.c, g.w, g.d);
-        Hit X = tracing_step<ASPH>(S, ray.pos, ray.dir, g.hint_obj, g.hint_shape, calls);
-        if (r == 0) o.Xc = X;
-        else if (r == 1) o.Xw = X;
-        else o.Xd = X;
-        if (X.shape < 0) {
-            all_hit = false;
-            break;
+    for (int phase = (RETR && probe) ? 0 : 1; phase < 2; ++phase) {
+        const bool probing = RETR && phase == 0;
+        all_hit = true;
+        BMO_NOUNROLL
+        for (int r = 0; r < 3; ++r) {
+            const RayS ray = pick_ray(r, g.c, g.w, g.d);
+            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, probing, probe_obj, false, nullptr);
+            if (r == 0) o.Xc = X;
+            else if (r == 1) o.Xw = X;
+            else o.Xd = X;
+            if (!probing && X.shape < 0) {
+                all_hit = false;
+                break;
+            }
+        }
+        if (probing) {
+            // the stored path holds only if all three rays still hit the same shape (System.jl:377-392)
+            if (o.Xc.shape >= 0 && o.Xw.shape >= 0 && o.Xd.shape >= 0 && o.Xc.shape == o.Xw.shape && o.Xw.shape == o.Xd.shape) break;
+            if (probe_missed) *probe_missed = true;
+            o.Xc = o.Xw = o.Xd = no_hit();
+            if (!fresh_allowed) {
+                o.status = BMO_NODE_RMAX;
+                return;
+            }
+            hint_obj = hint_shape = -1;
         }
     }
     if (!all_hit) {

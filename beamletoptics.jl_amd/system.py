@@ -338,12 +338,60 @@ def _fill_beams(scene, res, roots):
     return nodes
 
 
-def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=None):
-    """solve_system!(system, beam | beam group; r_max=100) — src/System.jl:444-468.
+class EngineSolution:
+    """A solved batch that stays resident on the GPU (bmo_trace_result*), so that the next solve_system can retrace it."""
 
-    Fresh (unsolved) beams only: the retrace pass of the reference is a no-op for them
-    (System.jl:197-206).  Mutates the beam objects (rays, intersections, children) and
-    appends detector data, exactly like the reference.  Returns the raw TraceResult.
+    def __init__(self, lib, handle, n_roots, kind):
+        self.lib, self.handle, self.n_roots, self.kind = lib, handle, n_roots, kind
+
+    def free(self):
+        if self.handle:
+            self.lib.bmo_result_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _engine_solve(scene, bundle, r_max, prev, device=0):
+    """One solve on the HIP engine: bmo_trace, or bmo_retrace when `prev` (an EngineSolution) is given."""
+    eng = Engine(scene, device)
+    try:
+        batch, keep = make_batch(scene, bundle)
+        h = C.c_void_p()
+        o = eng.opts(r_max)
+        if prev is None:
+            abi.check(eng.lib, eng.lib.bmo_trace(eng.handle, C.byref(batch), C.byref(o), C.byref(h)), "bmo_trace")
+        else:
+            abi.check(eng.lib, eng.lib.bmo_retrace(eng.handle, C.byref(batch), prev.handle, C.byref(o), C.byref(h)), "bmo_retrace")
+        sol = EngineSolution(eng.lib, h, bundle.n, bundle.kind)
+        res = eng.result_view(h)
+    finally:
+        eng.close()
+    return res, sol
+
+
+def release(beams):
+    """Free the solution kept for retracing (device memory of the segment log) of a solved beam / beam group."""
+    roots = beams.beams if isinstance(beams, bm.BeamGroup) else (list(beams) if isinstance(beams, (list, tuple)) else [beams])
+    for b in roots:
+        sol = getattr(b, "_solution", None)
+        if sol is not None:
+            sol.free()
+        b._solution = None
+
+
+def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=None):
+    """solve_system!(system, beam | beam group; r_max=100, retrace=true) — src/System.jl:444-468.
+
+    Fresh beams are traced; beams solved by an earlier call are RETRACED (System.jl:188-255, :326-428): the stored path is
+    re-walked against the system as it is now, the first ray of every root supplying the (possibly modified) head.
+    Mutates the beam objects (rays, intersections, children) and appends detector data, exactly like the reference
+    (detectors are not reset, Spotdetector.jl / PSFDetector.jl "Reset behavior").  Returns the raw TraceResult.
+    `_trace_fn(scene, bundle, r_max, prev) -> (TraceResult, solution)` swaps the backend (tests: the oracle).
     """
     if isinstance(beams, bm.BeamGroup):
         roots = beams.beams
@@ -353,15 +401,18 @@ def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=Non
         roots = [beams]
     bundle = bm.RayBundle.from_beams(roots)
     scene = CompiledScene(system, bundle.lambdas)
-    if _trace_fn is None:
-        eng = Engine(scene, device)
-        try:
-            res = eng.trace(bundle, r_max)
-        finally:
-            eng.close()
-    else:
-        res = _trace_fn(scene, bundle, r_max)
+    prev = getattr(roots[0], "_solution", None) if roots else None
+    if prev is not None:
+        same = all(getattr(b, "_solution", None) is prev and getattr(b, "_sol_index", -1) == i for i, b in enumerate(roots))
+        if not (same and prev.handle and prev.n_roots == len(roots) and prev.kind == bundle.kind):
+            prev = None  # a different grouping than the one that was solved: treat as fresh beams
+    if prev is not None and not retrace:
+        raise NotImplementedError("solve_system(retrace=False) on already solved beams")
+    fn = _trace_fn or (lambda sc, b, rm, pv: _engine_solve(sc, b, rm, pv, device))
+    res, sol = fn(scene, bundle, r_max, prev)
     _fill_beams(scene, res, roots)
+    for i, b in enumerate(roots):
+        b._solution, b._sol_index = sol, i
     for slot, det in enumerate(scene.detectors):
         hits = res.detector_hits(slot)
         if det.kind == cp.O_SPOT:

@@ -55,7 +55,11 @@ enum bmo_node_status {
     BMO_NODE_ERR_UNIT = 32,   /* refraction3d unit-length ArgumentError (OpticUtils.jl:33-35) */
     BMO_NODE_GAUSS_DIVERGED = 64, /* chief/waist/div did not hit same shape (System.jl:298-304) */
     BMO_NODE_BLOCKED = 128,   /* PolarizationFilter blocked ray (PolarizationFilter.jl:42) */
-    BMO_NODE_ERR_ORTHO = 256  /* E0 not orthogonal to dir, ErrorException (PolarizedRays.jl:54-56) */
+    BMO_NODE_ERR_ORTHO = 256, /* E0 not orthogonal to dir, ErrorException (PolarizedRays.jl:54-56) */
+    BMO_NODE_RETRACE_STALE = 512 /* retrace only: the stored beam had children, and the re-walk ended in a `nothing`
+                                    interaction without reaching the splitter.  The reference then keeps the stale
+                                    children untouched (System.jl:232-239 sets no cleanup flag); this library drops them
+                                    and raises this flag so the wrapper can fall back to the wrapped System. */
 };
 
 /* ------------------------------------------------------------------ shapes */
@@ -274,6 +278,26 @@ int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* tot
 /* Materialise host views (downloads + canonical ordering of the segment log). */
 int bmo_result_view(bmo_trace_result* res, bmo_trace_result_view* view);
 int bmo_result_free(bmo_trace_result* res);
+
+/* ------------------------------------------------------------------------------------------------
+ * Retracing: the second and later solve_system!(system, beams) on already solved beams —
+ * retrace_system! src/System.jl:188-255 (Beam), :326-428 (GaussianBeamlet), driven by solve_system! :444-461.
+ *
+ * `prev` is the result of the previous solve of the SAME beams (bmo_trace*, or an earlier bmo_retrace*); it stays valid and
+ * is not modified.  `scene` is the system as it is now (elements moved by the caller): it must have the object and shape
+ * numbering `prev` was solved with.  The batch supplies the root heads (first ray of every root beam; for Gaussian beamlets
+ * also lambda, w0, E0) and must have prev's root count and beam kind.
+ *
+ * Every stored ray is re-intersected with the object of its stored intersection only (or with the shape hinted by the
+ * preceding interaction), interacted, and the following stored ray is overwritten (replace!, Beam.jl:81-94); where the
+ * stored path ends or breaks the beam is cut, its children are dropped and normal tracing continues without a hint.
+ * Splitter children of an intact parent keep their identity and are re-walked with heads rewritten by the parent
+ * (children!, AbstractBeam.jl:62-76; a Gaussian child keeps its stored w0, Gaussian.jl:154-161).
+ * The result has the layout of a fresh trace.  n_intersect_calls counts the reference's intersect3d calls (one per
+ * re-walked ray and sub-ray, plus those of the continued trace).                                                     */
+int bmo_retrace(bmo_scene* scene, const bmo_ray_batch* in, bmo_trace_result* prev, const bmo_trace_opts* opts, bmo_trace_result** out);
+int bmo_retrace_device(bmo_scene* scene, bmo_device_batch* batch, bmo_trace_result* prev, const bmo_trace_opts* opts,
+                       bmo_trace_result** out);
 
 /* ------------------------------------------------------------------------------------------------
  * Detector read-out: intensity(psf::PSFDetector) — src/OpticalComponents/Detectors/PSFDetector.jl:190-237.

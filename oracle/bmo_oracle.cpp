@@ -870,20 +870,52 @@ bool refraction3d_ray(const Ray& ray, double n2, D3& out) {
 
 // interact3d dispatch for Beam{T,Ray} / Beam{T,PolarizedRay}.
 // Children (splitters) are appended to node.children with their first rays.
+// replace!(beam, interaction, index) Beam.jl:81-94 and the per-ray part of _modify_beam_head! Beam.jl:97-113:
+// position, direction, wavelength, refractive index (and polarization); the stored intersection is kept.
+void replace_ray_head(Ray& old, const Ray& nw) {
+    old.pos = nw.pos;
+    old.dir = nw.dir;
+    old.lambda = nw.lambda;
+    old.li = nw.li;
+    old.n = nw.n;
+    for (int k = 0; k < 3; ++k) old.E0[k] = nw.E0[k];
+}
+// children!(beam, [t, r]) AbstractBeam.jl:62-76: no children yet -> link and append; same number of children (a retrace)
+// -> _modify_beam_head! of each existing child (Beam.jl:97-113; Gaussian.jl:154-161: the three heads, lambda and E0 —
+// NOT w0, which keeps the value of the previous solve).
+void set_children(int kind, Node& node, std::vector<std::unique_ptr<Node>>& fresh) {
+    if (node.children.empty()) {
+        for (auto& ch : fresh) node.children.push_back(std::move(ch));
+    } else if (node.children.size() == fresh.size()) {
+        for (size_t i = 0; i < fresh.size(); ++i) {
+            Node& old = *node.children[i];
+            replace_ray_head(old.chief.rays.front(), fresh[i]->chief.rays.front());
+            if (kind == BMO_BEAM_GAUSSIAN) {
+                replace_ray_head(old.waist.rays.front(), fresh[i]->waist.rays.front());
+                replace_ray_head(old.div.rays.front(), fresh[i]->div.rays.front());
+                old.lambda = fresh[i]->lambda;
+                old.E0 = fresh[i]->E0;
+            }
+        }
+    }
+    node.status |= BMO_NODE_SPLIT;
+}
+
 Inter interact_beam(Ctx& C, Node& node, Beam& beam, const Ray& ray) {
     const Scene& S = *C.S;
     int oid = ray.isect.obj;
     const bmo_object& o = S.objects[oid];
     auto spawn = [&](const Ray& tr, const Ray& rf) {
+        std::vector<std::unique_ptr<Node>> fresh;
         for (const Ray* r : {&tr, &rf}) {
             auto ch = std::make_unique<Node>();
             ch->chief.rays.push_back(*r);
             ch->chief.parent = &beam;
             ch->parent = &node;
             ch->lambda = node.lambda;
-            node.children.push_back(std::move(ch));
+            fresh.push_back(std::move(ch));
         }
-        node.status |= BMO_NODE_SPLIT;
+        set_children(C.kind, node, fresh);
     };
     switch (o.kind) {
         case BMO_OBJ_MIRROR: return interact_mirror(C, ray, node);
@@ -1194,6 +1226,7 @@ GInter interact_gauss(Ctx& C, Node& g, int id /*1-based*/) {
                 t[k].n = nt;
                 r[k].n = nr_;
             }
+        std::vector<std::unique_ptr<Node>> fresh;
         for (int which = 0; which < 2; ++which) {
             auto ch = std::make_unique<Node>();
             Ray* rr = which == 0 ? t : r;
@@ -1205,9 +1238,9 @@ GInter interact_gauss(Ctx& C, Node& g, int id /*1-based*/) {
             ch->lambda = g.lambda;
             ch->w0 = w0;
             ch->E0 = which == 0 ? Et : Er;
-            g.children.push_back(std::move(ch));
+            fresh.push_back(std::move(ch));
         }
-        g.status |= BMO_NODE_SPLIT;
+        set_children(C.kind, g, fresh);
         return true;
     };
     switch (o.kind) {
@@ -1283,6 +1316,138 @@ void trace_gauss(Ctx& C, Node& g) {
     g.status |= BMO_NODE_RMAX;
 }
 
+// retrace_system!(system, beam::Beam)  System.jl:188-255
+void retrace_beam(Ctx& C, Node& node) {
+    const Scene& S = *C.S;
+    Beam& beam = node.chief;
+    bool cleanup_children = false, cleanup_tail = false, reset_intersection = false;
+    int cutoff = 0;
+    Hint hint;
+    const int n = (int)beam.rays.size();
+    for (int i = 1; i <= n; ++i) {
+        Ray& ray = beam.rays[i - 1];
+        if (!ray.has_isect) {
+            cleanup_children = cleanup_tail = reset_intersection = true;
+            cutoff = i;
+            break;
+        }
+        C.calls += 1;
+        Isect X;
+        if (!hint.set) {
+            X = intersect_object(S, ray.isect.obj, ray.pos, ray.dir);  // intersect3d(object(_intersection), ray)
+        } else {
+            X = intersect_shape(S, hint.shape, ray.pos, ray.dir);  // intersect3d(shape(_hint), ray)
+            if (X.hit) X.obj = hint.obj;
+        }
+        ray.has_isect = X.hit;
+        ray.isect = X;
+        if (!X.hit) {
+            cleanup_children = cleanup_tail = reset_intersection = true;
+            cutoff = i;
+            break;
+        }
+        Ray rcopy = ray;
+        Inter inter = interact_beam(C, node, beam, rcopy);
+        hint = inter.some ? inter.hint : Hint{};  // hint(::Nothing) = nothing, AbstractSystem.jl:82
+        if (!inter.some) {
+            node.status |= BMO_NODE_STOPPED;
+            if (!node.children.empty() && !(node.status & BMO_NODE_SPLIT)) node.status |= BMO_NODE_RETRACE_STALE;
+            if (n > i) {  // nothing is a valid interaction: only the disconnected tail goes
+                cleanup_tail = true;
+                cutoff = i;
+            }
+            break;
+        }
+        if (i < n) {
+            replace_ray_head(beam.rays[i], inter.ray);
+        } else {
+            cleanup_children = true;
+            beam.rays.push_back(inter.ray);
+            break;
+        }
+    }
+    if (cleanup_children) node.children.clear();
+    if (cleanup_tail) beam.rays.resize((size_t)cutoff);
+    if (reset_intersection) beam.rays.back().has_isect = false;
+}
+
+// retrace_system!(system, gauss)  System.jl:326-428
+bool retrace_gauss(Ctx& C, Node& g) {
+    const Scene& S = *C.S;
+    bool cleanup_children = false, cleanup_tail = false, reset_intersection = false;
+    int cutoff = 0;
+    Hint hint;
+    const int n_c = (int)g.chief.rays.size(), n_w = (int)g.waist.rays.size(), n_d = (int)g.div.rays.size();
+    if (!(n_c == n_w && n_w == n_d)) return false;  // error("Gaussian beamlet is broken")
+    for (int i = 1; i <= n_c; ++i) {
+        Ray& c = g.chief.rays[i - 1];
+        Ray& w = g.waist.rays[i - 1];
+        Ray& d = g.div.rays[i - 1];
+        if (!c.has_isect) {
+            cleanup_children = cleanup_tail = reset_intersection = true;
+            cutoff = i;
+            break;
+        }
+        int obj;
+        C.calls += 3;
+        if (!hint.set) {
+            obj = c.isect.obj;
+            for (Ray* r : {&c, &w, &d}) {
+                Isect X = intersect_object(S, obj, r->pos, r->dir);
+                r->has_isect = X.hit;
+                r->isect = X;
+            }
+        } else {
+            obj = hint.obj;
+            for (Ray* r : {&c, &w, &d}) {
+                Isect X = intersect_shape(S, hint.shape, r->pos, r->dir);
+                r->has_isect = X.hit;
+                r->isect = X;
+            }
+        }
+        if (!same_shape(c, w, d) || !c.has_isect) {
+            cleanup_children = cleanup_tail = reset_intersection = true;
+            cutoff = i;
+            break;
+        }
+        c.isect.obj = w.isect.obj = d.isect.obj = obj;
+        GInter gi = interact_gauss(C, g, i);
+        hint = gi.some ? gi.c.hint : Hint{};
+        if (!gi.some) {
+            g.status |= BMO_NODE_STOPPED;
+            if (!g.children.empty() && !(g.status & BMO_NODE_SPLIT)) g.status |= BMO_NODE_RETRACE_STALE;
+            if (n_c > i) {
+                cleanup_tail = true;
+                cutoff = i;
+            }
+            break;
+        }
+        if (i < n_c) {
+            replace_ray_head(g.chief.rays[i], gi.c.ray);
+            replace_ray_head(g.waist.rays[i], gi.w.ray);
+            replace_ray_head(g.div.rays[i], gi.d.ray);
+        } else {
+            cleanup_children = true;
+            g.chief.rays.push_back(gi.c.ray);
+            g.waist.rays.push_back(gi.w.ray);
+            g.div.rays.push_back(gi.d.ray);
+            break;
+        }
+    }
+    if (cleanup_children) g.children.clear();
+    if (cleanup_tail) {
+        g.chief.rays.resize((size_t)cutoff);
+        g.waist.rays.resize((size_t)cutoff);
+        g.div.rays.resize((size_t)cutoff);
+    }
+    if (reset_intersection) {
+        g.chief.rays.back().has_isect = false;
+        g.waist.rays.back().has_isect = false;
+        g.div.rays.back().has_isect = false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ result
 struct Result {
     bmo_trace_result_view view{};
@@ -1293,6 +1458,8 @@ struct Result {
     std::vector<int64_t> det_count, det_offset;
     std::vector<int32_t> det_node;
     std::vector<double> det_data;
+    std::vector<std::unique_ptr<Node>> roots;  // the solved beam trees (input of a later bmo_cpu_retrace)
+    int kind = 0;
 };
 
 struct RootOut {
@@ -1305,11 +1472,12 @@ struct RootOut {
 
 int rec_planes_for(int kind) { return kind == BMO_BEAM_RAY ? 11 : (kind == BMO_BEAM_POLARIZED ? 17 : 33); }
 
-void solve_root(const Scene& S, const bmo_ray_batch* in, int r_max, int64_t i, RootOut& out) {
+// Root beam i of the batch; with `into` the heads of an already solved root are overwritten instead (the caller of a
+// second solve_system! may have moved the source: first ray, and for a Gaussian also lambda, w0, E0).
+void load_root(const bmo_ray_batch* in, int64_t i, Node& root, bool into) {
     int64_t n = in->n;
     const double* P = in->planes;
     auto pl = [&](int k) { return P[(size_t)k * n + i]; };
-    auto root = std::make_unique<Node>();
     int li = in->lambda_idx[i];
     auto mk = [&](int base, double lam, double nn) {
         Ray r;
@@ -1320,28 +1488,51 @@ void solve_root(const Scene& S, const bmo_ray_batch* in, int r_max, int64_t i, R
         r.n = nn;
         return r;
     };
+    auto put = [&](Beam& b, const Ray& r) {
+        if (into) replace_ray_head(b.rays.front(), r);
+        else b.rays.push_back(r);
+    };
     if (in->kind == BMO_BEAM_GAUSSIAN) {
         double lam = pl(18), nn = pl(19);
-        root->chief.rays.push_back(mk(0, lam, nn));
-        root->waist.rays.push_back(mk(6, lam, nn));
-        root->div.rays.push_back(mk(12, lam, nn));
-        root->lambda = lam;
-        root->w0 = pl(20);
-        root->E0 = Cx{pl(21), pl(22)};
+        put(root.chief, mk(0, lam, nn));
+        put(root.waist, mk(6, lam, nn));
+        put(root.div, mk(12, lam, nn));
+        root.lambda = lam;
+        root.w0 = pl(20);
+        root.E0 = Cx{pl(21), pl(22)};
     } else {
         Ray r = mk(0, pl(6), pl(7));
         if (in->kind == BMO_BEAM_POLARIZED)
             for (int k = 0; k < 3; ++k) r.E0[k] = Cx{pl(8 + 2 * k), pl(9 + 2 * k)};
-        root->chief.rays.push_back(r);
-        root->lambda = pl(6);
+        put(root.chief, r);
+        root.lambda = pl(6);
     }
+}
+
+// Deep copy of a solved tree (parent links re-pointed into the copy).
+std::unique_ptr<Node> clone_tree(const Node& src, Node* parent) {
+    auto n = std::make_unique<Node>();
+    n->chief.rays = src.chief.rays;
+    n->waist.rays = src.waist.rays;
+    n->div.rays = src.div.rays;
+    n->parent = parent;
+    n->chief.parent = parent ? &parent->chief : nullptr;
+    n->lambda = src.lambda;
+    n->w0 = src.w0;
+    n->E0 = src.E0;
+    n->status = 0;
+    for (auto& ch : src.children) n->children.push_back(clone_tree(*ch, n.get()));
+    return n;
+}
+
+// solve_system!(system, beam; r_max, retrace)  System.jl:444-461
+void solve_tree(const Scene& S, int kind, int r_max, bool retrace, std::unique_ptr<Node> root, RootOut& out) {
     Ctx C;
     C.S = &S;
-    C.kind = in->kind;
+    C.kind = kind;
     C.r_max = r_max;
     C.det.resize(S.n_detectors);
     out.det_node_local.resize(S.n_detectors);
-    // solve_system!  System.jl:444-461 (fresh beams: retrace_system! is a no-op, :197-206)
     std::deque<Node*> queue{root.get()};
     while (!queue.empty()) {
         Node* cur = queue.front();
@@ -1350,9 +1541,16 @@ void solve_root(const Scene& S, const bmo_ray_batch* in, int r_max, int64_t i, R
         out.order.push_back(cur);
         std::vector<size_t> before(S.n_detectors);
         for (int d = 0; d < S.n_detectors; ++d) before[d] = C.det[d].size();
+        cur->status = 0;
+        if (retrace) {  // fresh one-ray beams: a no-op (System.jl:197-206)
+            if (kind == BMO_BEAM_GAUSSIAN) retrace_gauss(C, *cur);
+            else retrace_beam(C, *cur);
+        }
         // solve_leaf! System.jl:470-475
-        if (in->kind == BMO_BEAM_GAUSSIAN) trace_gauss(C, *cur);
-        else trace_beam(C, *cur);
+        if (!cur->chief.rays.back().has_isect) {
+            if (kind == BMO_BEAM_GAUSSIAN) trace_gauss(C, *cur);
+            else trace_beam(C, *cur);
+        }
         for (int d = 0; d < S.n_detectors; ++d)
             for (size_t k = before[d]; k < C.det[d].size(); ++k) out.det_node_local[d].push_back(idx);
         for (auto& ch : cur->children) queue.push_back(ch.get());
@@ -1360,6 +1558,12 @@ void solve_root(const Scene& S, const bmo_ray_batch* in, int r_max, int64_t i, R
     out.det = std::move(C.det);
     out.calls = C.calls;
     out.root = std::move(root);
+}
+
+void solve_root(const Scene& S, const bmo_ray_batch* in, int r_max, int64_t i, RootOut& out) {
+    auto root = std::make_unique<Node>();
+    load_root(in, i, *root, false);
+    solve_tree(S, in->kind, r_max, true, std::move(root), out);
 }
 
 void write_ray(std::vector<double>& rec, size_t nrec, size_t r, int base, const Ray& ray) {
@@ -1379,6 +1583,22 @@ void write_ray(std::vector<double>& rec, size_t nrec, size_t r, int base, const 
 
 }  // namespace
 
+static int finalize(const Scene& S, const bmo_ray_batch* in, std::vector<RootOut>& outs, void** out_handle, bmo_trace_result_view* view);
+
+template <class F>
+static void parallel_roots(int64_t n, int n_threads, F&& body) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n) n_threads = (int)std::max<int64_t>(1, n);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        th.emplace_back([&, t]() {
+            int64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+            for (int64_t i = lo; i < hi; ++i) body(i);
+        });
+    }
+    for (auto& x : th) x.join();
+}
+
 extern "C" {
 
 const char* bmo_cpu_last_error(void) { return g_err.c_str(); }
@@ -1396,18 +1616,43 @@ int bmo_cpu_trace(const bmo_scene_desc* desc, const bmo_ray_batch* in, const bmo
     }
     int64_t n = in->n;
     std::vector<RootOut> outs((size_t)n);
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > n) n_threads = (int)std::max<int64_t>(1, n);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) {
-        th.emplace_back([&, t]() {
-            int64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
-            for (int64_t i = lo; i < hi; ++i) solve_root(S, in, opts->r_max, i, outs[(size_t)i]);
-        });
-    }
-    for (auto& x : th) x.join();
+    parallel_roots(n, n_threads, [&](int64_t i) { solve_root(S, in, opts->r_max, i, outs[(size_t)i]); });
+    return finalize(S, in, outs, out_handle, view);
+}
 
+// Second and later solve_system! on already solved beams (System.jl:444-461 with retrace = true): every beam of the previous
+// solution is retraced (System.jl:188-255 / :326-428) against the scene `desc` (same object / shape numbering, moved
+// elements), then traced on from wherever the stored path ended or broke.  `in` supplies the root heads (same count as the
+// previous batch).  The previous result stays valid.
+int bmo_cpu_retrace(const bmo_scene_desc* desc, const bmo_ray_batch* in, const bmo_trace_opts* opts, int n_threads, void* prev_handle,
+                    void** out_handle, bmo_trace_result_view* view) {
+    Scene S;
+    if (!build_scene(desc, S)) return BMO_ERR_INVALID;
+    if (!in || !opts || !out_handle || !view || !prev_handle) {
+        g_err = "null argument";
+        return BMO_ERR_INVALID;
+    }
+    const Result* prev = static_cast<const Result*>(prev_handle);
+    int64_t n = in->n;
+    if ((int64_t)prev->roots.size() != n || prev->kind != in->kind) {
+        g_err = "retrace: batch does not match the previous solution (root count / beam kind)";
+        return BMO_ERR_INVALID;
+    }
+    std::vector<RootOut> outs((size_t)n);
+    parallel_roots(n, n_threads, [&](int64_t i) {
+        std::unique_ptr<Node> root = clone_tree(*prev->roots[(size_t)i], nullptr);
+        load_root(in, i, *root, true);
+        solve_tree(S, in->kind, opts->r_max, true, std::move(root), outs[(size_t)i]);
+    });
+    return finalize(S, in, outs, out_handle, view);
+}
+
+}  // extern "C"
+
+static int finalize(const Scene& S, const bmo_ray_batch* in, std::vector<RootOut>& outs, void** out_handle, bmo_trace_result_view* view) {
+    const int64_t n = in->n;
     auto* R = new Result();
+    R->kind = in->kind;
     int rp = rec_planes_for(in->kind);
     size_t nnodes = 0, nrec = 0;
     for (auto& o : outs) {
@@ -1521,10 +1766,13 @@ int bmo_cpu_trace(const bmo_scene_desc* desc, const bmo_ray_batch* in, const bmo
     v.det_offset = R->det_offset.data();
     v.det_node = R->det_node.data();
     v.det_data = R->det_data.data();
+    for (auto& o : outs) R->roots.push_back(std::move(o.root));
     *view = v;
     *out_handle = R;
     return BMO_OK;
 }
+
+extern "C" {
 
 int bmo_cpu_result_free(void* handle) {
     delete static_cast<Result*>(handle);

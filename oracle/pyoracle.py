@@ -30,6 +30,8 @@ def lib():
         L.bmo_cpu_trace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.c_int,
                                     C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
         L.bmo_cpu_result_free.argtypes = [C.c_void_p]
+        L.bmo_cpu_retrace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.c_int, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
         L.bmo_cpu_last_error.restype = C.c_char_p
         L.bmo_cpu_sdf.restype = C.c_double
         L.bmo_cpu_sdf.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, dp]
@@ -53,26 +55,56 @@ def _d(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def trace(scene, bundle, r_max=100, threads=1):
-    """Reference-algorithm CPU trace -> abi.TraceResult (same layout as the engine's)."""
+class Solution:
+    """A solved batch kept alive on the oracle side (the beam trees), so that it can be retraced."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def free(self):
+        if self.handle:
+            lib().bmo_cpu_result_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def trace(scene, bundle, r_max=100, threads=1, keep=False, prev=None):
+    """Reference-algorithm CPU trace -> abi.TraceResult (same layout as the engine's).
+
+    keep=True returns (TraceResult, Solution); prev=Solution re-solves those beams (retrace_system!, System.jl:188-255) against
+    `scene` with `bundle` supplying the root heads."""
     L = lib()
-    batch, keep = bmo.make_batch(scene, bundle)
+    batch, keepalive = bmo.make_batch(scene, bundle)
     o = abi.TraceOpts()
     o.r_max, o.device, o.record_segments, o.reserved = int(r_max), 0, 1, 0
     h = C.c_void_p()
     v = abi.ResultView()
-    rc = L.bmo_cpu_trace(C.byref(scene.desc), C.byref(batch), C.byref(o), int(threads), C.byref(h), C.byref(v))
+    if prev is None:
+        rc = L.bmo_cpu_trace(C.byref(scene.desc), C.byref(batch), C.byref(o), int(threads), C.byref(h), C.byref(v))
+    else:
+        rc = L.bmo_cpu_retrace(C.byref(scene.desc), C.byref(batch), C.byref(o), int(threads), prev.handle, C.byref(h), C.byref(v))
     if rc != 0:
         raise RuntimeError(f"bmo_cpu_trace failed: {L.bmo_cpu_last_error().decode()}")
-    try:
-        return abi.TraceResult(v)
-    finally:
-        L.bmo_cpu_result_free(h)
+    res = abi.TraceResult(v)
+    if keep:
+        return res, Solution(h)
+    L.bmo_cpu_result_free(h)
+    return res
 
 
 def solve_system(system, beams, r_max=100, threads=1):
     """solve_system! computed by the oracle (fills the same Python beam objects)."""
-    return bmo.solve_system(system, beams, r_max=r_max, _trace_fn=lambda sc, b, rm: trace(sc, b, rm, threads))
+    def fn(sc, b, rm, prev):
+        res, sol = trace(sc, b, rm, threads, keep=True, prev=prev)
+        sol.n_roots, sol.kind = b.n, b.kind
+        return res, sol
+
+    return bmo.solve_system(system, beams, r_max=r_max, _trace_fn=fn)
 
 
 def sdf(scene, shape, p):

@@ -23,7 +23,15 @@ struct NodeE {
     int root, parent, nseg, status, li, hit_det;
     unsigned long long key;
     double lambda, hit[9];
+    int old = -1;  // node of the previous solution this beam re-walks (retrace), -1 = fresh
 };
+// node index of every root beam in a canonical result view (roots are the nodes without parent, in bundle order)
+std::vector<int> old_roots(const bmo_trace_result_view* prev) {
+    std::vector<int> r;
+    for (int64_t i = 0; i < prev->n_nodes; ++i)
+        if (prev->node_parent[i] < 0) r.push_back((int)i);
+    return r;
+}
 struct ResultE {
     std::vector<int32_t> root, parent, first_child, first_rec, nseg, status, rec_obj, rec_shape, det_node;
     std::vector<double> aux, rec, det;
@@ -31,7 +39,10 @@ struct ResultE {
 };
 
 template <int KIND>
-void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v) {
+void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v,
+         const bmo_trace_result_view* prev = nullptr) {
+    std::vector<int> oroot;
+    if (prev) oroot = old_roots(prev);
     SceneView S;
     S.objects = d->objects;
     S.shapes = d->shapes;
@@ -65,6 +76,10 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
         r.flags = (1 < opts->r_max) ? 0 : 1;
         r.opl = 0;
         nodes[j] = NodeE{(int)j, -1, 1, 0, in->lambda_idx[j], -1, ((unsigned long long)j) << 32, P[6 * n + j], {0}};
+        if (prev) {
+            nodes[j].old = oroot[j];
+            r.flags = 0;  // the retrace walk ignores r_max (System.jl:197)
+        }
     }
     unsigned long long calls = 0;
     int steps = 0;
@@ -86,11 +101,26 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             X.n = {0, 0, 0};
             NodeE nd = nodes[r.node];
             double opl_next = 0;
-            if (r.flags & 1) {
+            // retrace context (System.jl:188-255)
+            const int old = nd.old;
+            bool probe = false, fresh_allowed = true, missed = false;
+            int probe_obj = -1, old_n = 0;
+            int hobj = r.hobj, hshape = r.hshape;
+            if (old >= 0) {
+                old_n = prev->node_nseg[old];
+                probe_obj = prev->rec_obj[prev->node_first_rec[old] + r.k];
+                fresh_allowed = r.k + 1 < opts->r_max;
+                probe = probe_obj >= 0;
+                if (!probe) {  // stored ray without intersection: cleanup, trace_system! goes on without a hint
+                    missed = true;
+                    hobj = hshape = -1;
+                }
+            }
+            if ((r.flags & 1) || (old >= 0 && !probe && !fresh_allowed)) {
                 status = BMO_NODE_RMAX;
             } else {
-                X = tracing_step<true>(S, r.ray.pos, r.ray.dir, r.hobj, r.hshape, c);
-                if (X.shape < 0) status = BMO_NODE_MISS;
+                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, probe, probe_obj, fresh_allowed, &missed);
+                if (X.shape < 0) status = (old >= 0 && missed && !fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 else {
                     interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
                     status = o.status;
@@ -102,7 +132,10 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             }
             calls += c;
             r.X = X;
+            const bool still = old >= 0 && probe && !missed;  // the stored path held at this ray
+            const bool old_kids = still && (prev->node_status[old] & BMO_NODE_SPLIT);
             if (!survive) {
+                if (old_kids && o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
                 if (o.det_slot >= 0) {
@@ -118,21 +151,30 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                 q.hobj = o.hint_obj;
                 q.hshape = o.hint_shape;
                 q.flags = (r.k + 2 < opts->r_max) ? 0 : 1;
+                if (still && r.k + 1 < old_n) {
+                    q.flags = 0;  // replace!: the next stored ray is re-walked whatever r_max says
+                } else {
+                    nodes[r.node].old = -1;
+                    if (still) q.hobj = q.hshape = -1;  // push!, then trace_system! starts over without a hint
+                }
                 q.opl = opl_next;
                 surv.push_back(q);
+            } else {
+                nodes[r.node].old = -1;
             }
             if (o.outcome == OUT_SPLIT && !(r.flags & 1) && X.shape >= 0) {
                 unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
                 for (int w = 0; w < 2; ++w) {
                     NodeE c2{(int)root, r.node, 1, 0, nd.li, -1, (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull)),
                              nd.lambda, {0}};
+                    if (old_kids) c2.old = prev->node_first_child[old] + w;  // children!: _modify_beam_head! of the stored child
                     nodes.push_back(c2);
                     Rec q;
                     q.ray = w == 0 ? o.next : o.refl;
                     q.node = (int)nodes.size() - 1;
                     q.k = 0;
                     q.hobj = q.hshape = -1;
-                    q.flags = (1 < opts->r_max) ? 0 : 1;
+                    q.flags = (c2.old >= 0 || 1 < opts->r_max) ? 0 : 1;
                     q.opl = opl_next;
                     kids.push_back(q);
                 }
@@ -231,8 +273,12 @@ struct GNode {
     double lambda, l0, w0;
     cx E0;
     double hit[27];
+    int old = -1;
 };
-void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v) {
+void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v,
+               const bmo_trace_result_view* prev = nullptr) {
+    std::vector<int> oroot;
+    if (prev) oroot = old_roots(prev);
     SceneView S;
     S.objects = d->objects;
     S.shapes = d->shapes;
@@ -285,6 +331,10 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
         nd.lambda = r.g.lambda;
         nd.w0 = r.g.w0;
         nd.E0 = r.g.E0;
+        if (prev) {
+            nd.old = oroot[j];
+            r.flags = 0;
+        }
         nodes[j] = nd;
     }
     unsigned long long calls = 0;
@@ -298,16 +348,34 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             r.o.Xc = r.o.Xw = r.o.Xd = no_hit();
             r.o.outcome = OUT_MISS;
             r.o.det_slot = -1;
-            if (r.flags & 1) status = BMO_NODE_RMAX;
+            const int old = nodes[r.node].old;
+            bool probe = false, fresh_allowed = true, missed = false;
+            int probe_obj = -1, old_n = 0;
+            if (old >= 0) {
+                old_n = prev->node_nseg[old];
+                probe_obj = prev->rec_obj[prev->node_first_rec[old] + r.k];
+                fresh_allowed = r.k + 1 < opts->r_max;
+                probe = probe_obj >= 0;
+                if (!probe) {
+                    missed = true;
+                    r.g.hint_obj = r.g.hint_shape = -1;
+                }
+            }
+            if ((r.flags & 1) || (old >= 0 && !probe && !fresh_allowed)) status = BMO_NODE_RMAX;
             else {
-                gauss_step<true>(S, r.g, r.o, c);
+                gauss_step<true, true>(S, r.g, r.o, c, probe, probe_obj, fresh_allowed, &missed);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
                 else if (r.o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
             }
             calls += c;
+            const bool still = old >= 0 && probe && !missed;
+            const bool old_kids = still && (prev->node_status[old] & BMO_NODE_SPLIT);
+            const bool keep_walking = survive && still && r.k + 1 < old_n;
+            if (!keep_walking) nodes[r.node].old = -1;
             if (!survive) {
+                if (old_kids && r.o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
                 if (r.o.det_slot >= 0 && !(r.flags & 1)) {
@@ -337,9 +405,11 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                 q.flags = fl;
                 return q;
             };
-            if (survive)
-                surv.push_back(next(r.o.nc, r.o.nw, r.o.nd, r.node, r.k + 1, r.o.hint_obj, r.o.hint_shape, (r.k + 2 < opts->r_max) ? 0 : 1, r.o.lenA,
-                                    r.o.lenB, r.o.oplC, r.o.oplW, r.o.oplD, nodes[r.node]));
+            if (survive) {
+                const bool pushed = still && !keep_walking;  // push!, then trace_system! starts over without a hint
+                surv.push_back(next(r.o.nc, r.o.nw, r.o.nd, r.node, r.k + 1, pushed ? -1 : r.o.hint_obj, pushed ? -1 : r.o.hint_shape,
+                                    (keep_walking || r.k + 2 < opts->r_max) ? 0 : 1, r.o.lenA, r.o.lenB, r.o.oplC, r.o.oplW, r.o.oplD, nodes[r.node]));
+            }
             if (!(r.flags & 1) && r.o.outcome == OUT_SPLIT) {
                 unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
                 for (int w = 0; w < 2; ++w) {
@@ -354,8 +424,12 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                     c2.l0 = r.o.child_l0;
                     c2.w0 = r.o.child_w0;
                     c2.E0 = w == 0 ? r.o.Et : r.o.Er;
+                    if (old_kids) {
+                        c2.old = prev->node_first_child[old] + w;
+                        c2.w0 = prev->node_aux[4 * c2.old + 0];  // _modify_beam_head! (Gaussian.jl:154-161) leaves w0 alone
+                    }
                     nodes.push_back(c2);
-                    const int fl = (1 < opts->r_max) ? 0 : 1;
+                    const int fl = (c2.old >= 0 || 1 < opts->r_max) ? 0 : 1;
                     if (w == 0) kids.push_back(next(r.o.nc, r.o.nw, r.o.nd, (int)nodes.size() - 1, 0, -1, -1, fl, 0.0, r.o.child_l0, r.o.oplC, 0.0, 0.0, c2));
                     else kids.push_back(next(r.o.rc, r.o.rw, r.o.rd, (int)nodes.size() - 1, 0, -1, -1, fl, 0.0, r.o.child_l0, r.o.oplC, 0.0, 0.0, c2));
                 }
@@ -457,6 +531,21 @@ int bmo_emu_trace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_tr
     if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v);
     else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v);
     else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v);
+    else {
+        delete R;
+        return BMO_ERR_UNSUPPORTED;
+    }
+    *handle = R;
+    return BMO_OK;
+}
+// second solve of already solved beams: `prev` is the canonical view of the previous solution (any backend's)
+int bmo_emu_retrace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, const bmo_trace_result_view* prev, void** handle,
+                    bmo_trace_result_view* v) {
+    if (!prev || prev->n_roots != in->n || prev->beam_kind != in->kind) return BMO_ERR_INVALID;
+    auto* R = new ResultE();
+    if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v, prev);
+    else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v, prev);
+    else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v, prev);
     else {
         delete R;
         return BMO_ERR_UNSUPPORTED;

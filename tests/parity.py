@@ -12,8 +12,8 @@ EMU = os.path.join(ROOT, "tests", "emu", "libbmo_emu.so")
 _emu = None
 
 
-def emu_trace(scene, bundle, r_max=100):
-    """Host build of the engine's lane code (tests/emu) — test-only."""
+def emu_trace(scene, bundle, r_max=100, prev=None):
+    """Host build of the engine's lane code (tests/emu) — test-only.  prev = TraceResult of the previous solve => retrace."""
     global _emu
     if _emu is None:
         import subprocess
@@ -23,12 +23,18 @@ def emu_trace(scene, bundle, r_max=100):
         _emu.bmo_emu_trace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.POINTER(C.c_void_p),
                                        C.POINTER(abi.ResultView)]
         _emu.bmo_emu_free.argtypes = [C.c_void_p]
+        _emu.bmo_emu_retrace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.POINTER(abi.ResultView),
+                                         C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
     batch, keep = bmo.make_batch(scene, bundle)
     o = abi.TraceOpts()
     o.r_max, o.device, o.record_segments, o.reserved = int(r_max), 0, 1, 0
     h = C.c_void_p()
     v = abi.ResultView()
-    rc = _emu.bmo_emu_trace(C.byref(scene.desc), C.byref(batch), C.byref(o), C.byref(h), C.byref(v))
+    if prev is None:
+        rc = _emu.bmo_emu_trace(C.byref(scene.desc), C.byref(batch), C.byref(o), C.byref(h), C.byref(v))
+    else:
+        pv = prev.as_view()
+        rc = _emu.bmo_emu_retrace(C.byref(scene.desc), C.byref(batch), C.byref(o), C.byref(pv), C.byref(h), C.byref(v))
     assert rc == 0, rc
     try:
         return abi.TraceResult(v)

@@ -1,0 +1,240 @@
+"""Retracing: the second solve_system! on solved beams — retrace_system! src/System.jl:188-255 (Beam),
+:326-428 (GaussianBeamlet), solve_system! :444-461.
+
+CPU part: the oracle reproduces the reference's retrace KATs (test/runtests.jl:2267-2287, :2568-2591, :2619-2651), and the
+engine's lane code (host emulator) equals the oracle bit for bit on perturbed BASELINE scenes.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bmo_amd as bmo
+import scenes
+from parity import compare, emu_trace
+
+mm = 1e-3
+
+
+def approx(a, b, atol=1e-12):
+    return np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1.4901161193847656e-8, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------ reference KATs
+def test_kat_three_mirrors_retrace_after_move(oracle):  # runtests.jl:2243-2287
+    m1, m2, m3 = (bmo.SquarePlanoMirror2D(1.0) for _ in range(3))
+    bmo.translate3d(m2, [2, 0, 0])
+    bmo.translate3d(m3, [2, 2, 0])
+    bmo.zrotate3d(m1, math.radians(-90))
+    bmo.yrotate3d(m1, math.radians(45))
+    bmo.zrotate3d(m2, math.radians(45))
+    bmo.xrotate3d(m3, math.radians(135))
+    system = bmo.StaticSystem([m1, m2, m3])
+    ray = bmo.PolarizedRay([0.0, 0, -2], [0, 0, 1], 1000e-9, [1, 0, 0])
+    beam = bmo.Beam(ray)
+    oracle.solve_system(system, beam)
+    E = [r.E0 for r in beam.rays]
+    assert approx(E[0].real, [1, 0, 0]) and approx(E[1].real, [0, 0, -1]) and approx(E[2].real, [0, 0, 1]) and approx(E[3].real, [0, -1, 0])
+    assert beam.length() == 6.0
+    # "y-Polarization": polarization!(ray, lin_y_pol); translate3d!(m3, [0, 2, 0]); solve_system! retraces
+    beam.rays[0].E0 = np.array([0, 5, 0], dtype=np.complex128)
+    bmo.translate3d(m3, [0, 2, 0])
+    res = oracle.solve_system(system, beam)
+    E = [r.E0 for r in beam.rays]
+    assert approx(E[0].real, [0, 5, 0]) and approx(E[1].real, [0, -5, 0]) and approx(E[2].real, [5, 0, 0]) and approx(E[3].real, [-5, 0, 0])
+    assert beam.length() == 8.0
+    assert res.n_intersect_calls == 3 + 3  # three re-walked rays (one intersect3d each), then trace_all of the open tail
+
+
+def test_kat_plate_beamsplitter_retrace_backside(oracle):  # runtests.jl:2540-2591
+    N0 = 1.5
+    pbs = bmo.RectangularPlateBeamsplitter(36 * mm, 25 * mm, 1 * mm, lambda n: N0)
+    system = bmo.System([pbs])
+    beam = bmo.Beam([0, -50 * mm, 0], [0, 1, 0], 1e-6)
+    bmo.zrotate3d(pbs, math.radians(45))
+    oracle.solve_system(system, beam)
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays
+    assert (len(p), len(t), len(r)) == (1, 2, 1)
+    bmo.zrotate3d(pbs, math.pi)
+    oracle.solve_system(system, beam)  # retrace: the stored coating hit turns into a substrate hit, children are rebuilt
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays
+    assert (len(p), len(t), len(r)) == (2, 1, 2)
+    assert [x.n for x in p] == [1, N0] and [x.n for x in t] == [1] and [x.n for x in r] == [N0, 1]
+    assert approx(p[0].dir, t[-1].dir) and approx(r[-1].dir, [1, 0, 0])
+
+
+def test_kat_cube_beamsplitter_retrace_rotations(oracle):  # runtests.jl:2594-2651
+    N0 = 1.5
+    cbs = bmo.CubeBeamsplitter(25e-3, lambda n: N0)
+    bmo.translate3d(cbs, [0, 50 * mm, 0])
+    system = bmo.System([cbs])
+    beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
+    oracle.solve_system(system, beam)
+    bmo.zrotate3d(cbs, math.pi / 2)
+    oracle.solve_system(system, beam)
+    t = beam.children[0].rays
+    assert np.array_equal(t[-1].dir, beam.rays[0].dir) and np.array_equal(t[-1].dir, [0, 1, 0])  # :2629-2630 (exact)
+    bmo.zrotate3d(cbs, math.pi / 2)
+    oracle.solve_system(system, beam)
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays
+    assert (len(p), len(t), len(r)) == (2, 2, 2)
+    assert [x.n for x in p] == [1, N0] and [x.n for x in t] == [N0, 1] and [x.n for x in r] == [N0, 1]
+    assert approx(t[-1].dir, p[0].dir) and approx(r[-1].dir, [-1, 0, 0])
+
+
+def test_retrace_of_unchanged_system_reproduces_the_solution(oracle):
+    """Re-walking an unmoved system gives the same rays; only the call count differs (1 per stored ray instead of M)."""
+    system, _ = scenes.c2_scene()
+    bundle = scenes.c2_bundle(64)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    a, sol = oracle.trace(scene, bundle, 20, keep=True)
+    b = oracle.trace(scene, bundle, 20, prev=sol)
+    b.n_intersect_calls = a.n_intersect_calls
+    compare(b, a, rtol=0.0, label="retrace(unchanged)")
+
+
+# ------------------------------------------------------------------------------------------------ lane code == oracle
+def _perturb_c2(parts, case):
+    bs, det_t, det_r = parts["bs"], parts["det_t"], parts["det_r"]
+    if case == "tilt_splitter":
+        bmo.xrotate3d(bs, math.radians(0.7))
+    elif case == "move_detector_away":  # the transmitted arm now runs into nothing: stored last rays lose their intersection
+        bmo.translate3d(det_t, [0, 0.5, 0])
+    elif case == "shift_train":  # a lens moves sideways: some stored hits are lost -> cut, children dropped, fresh trace
+        bmo.translate3d(parts["objs"][0], [0.9 * mm, 0, 0])
+    elif case == "remove_splitter_from_path":
+        bmo.translate3d(bs, [0.2, 0, 0])
+    else:
+        raise ValueError(case)
+
+
+def _c2_with_parts():
+    objs = scenes.miniscope_objects()
+    y0 = 0.332 * mm
+    bs = bmo.ThinBeamsplitter(10 * mm)
+    bmo.xrotate3d(bs, math.radians(45))
+    bmo.translate3d(bs, [0, y0, 30 * mm])
+    det_t = bmo.Spotdetector(5 * mm)
+    bmo.xrotate3d(det_t, math.radians(90))
+    bmo.translate3d(det_t, [0, y0, 34 * mm])
+    det_r = bmo.Spotdetector(5 * mm)
+    bmo.translate3d(det_r, [0, y0 - 4 * mm, 30 * mm])
+    return bmo.System(objs + [bs, det_t, det_r]), dict(objs=objs, bs=bs, det_t=det_t, det_r=det_r)
+
+
+RETRACE_CASES = ["tilt_splitter", "move_detector_away", "shift_train", "remove_splitter_from_path"]
+
+
+def retrace_pair(kind, case, n, r_max=20):
+    """(scene0, scene1, bundle): a BASELINE scene before and after a kinematic move."""
+    system, parts = _c2_with_parts()
+    if kind == "ray":
+        bundle = scenes.c2_bundle(n)
+    elif kind == "gauss":
+        bundle = scenes.c3_bundle(n)
+    else:
+        bundle = scenes.polarized_bundle(n, center=[0, -5 * mm, 0], direction=[0, 1, 0], diameter=1.2 * mm)
+    scene0 = bmo.CompiledScene(system, bundle.lambdas)
+    _perturb_c2(parts, case)
+    scene1 = bmo.CompiledScene(system, bundle.lambdas)
+    return scene0, scene1, bundle
+
+
+@pytest.mark.parametrize("case", RETRACE_CASES)
+@pytest.mark.parametrize("kind", ["ray", "gauss", "pol"])
+def test_emulator_retrace_equals_oracle(oracle, kind, case):
+    scene0, scene1, bundle = retrace_pair(kind, case, 96)
+    a0, sol = oracle.trace(scene0, bundle, 20, keep=True)
+    a1, sol1 = oracle.trace(scene1, bundle, 20, keep=True, prev=sol)
+    e0 = emu_trace(scene0, bundle, 20)
+    compare(e0, a0, rtol=0.0, label=f"{kind}/{case} first solve")
+    e1 = emu_trace(scene1, bundle, 20, prev=e0)
+    assert not (a1.node_status & 512).any()
+    compare(e1, a1, rtol=0.0, label=f"{kind}/{case} retrace")
+    # the move really changed the solution, and the retrace is not simply a fresh trace of the moved system
+    fresh = oracle.trace(scene1, bundle, 20)
+    assert a1.n_intersect_calls != fresh.n_intersect_calls
+    # a third solve (retrace of a retraced solution) after moving back
+    a2 = oracle.trace(scene0, bundle, 20, prev=sol1)
+    e2 = emu_trace(scene0, bundle, 20, prev=e1)
+    compare(e2, a2, rtol=0.0, label=f"{kind}/{case} retrace back")
+
+
+def test_retrace_with_smaller_r_max(oracle):
+    scene0, scene1, bundle = retrace_pair("ray", "shift_train", 64)
+    a0, sol = oracle.trace(scene0, bundle, 20, keep=True)
+    e0 = emu_trace(scene0, bundle, 20)
+    for r_max in (1, 2, 3, 5, 8):
+        a1 = oracle.trace(scene1, bundle, r_max, prev=sol)
+        e1 = emu_trace(scene1, bundle, r_max, prev=e0)
+        compare(e1, a1, rtol=0.0, label=f"r_max={r_max}")
+
+
+def test_retrace_rejects_mismatched_batch(oracle):
+    scene0, scene1, bundle = retrace_pair("ray", "tilt_splitter", 16)
+    a0, sol = oracle.trace(scene0, bundle, 20, keep=True)
+    with pytest.raises(RuntimeError):
+        oracle.trace(scene1, scenes.c2_bundle(8), 20, prev=sol)
+
+
+# ------------------------------------------------------------------------------------------------ HIP engine == oracle
+def _engine_solve(scene, bundle, r_max, prev=None):
+    return bmo.system._engine_solve(scene, bundle, r_max, prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RETRACE_CASES)
+@pytest.mark.parametrize("kind,rtol", [("ray", 0.0), ("gauss", 1e-10), ("pol", 1e-10)])
+def test_gpu_retrace_equals_oracle(oracle, kind, rtol, case):
+    scene0, scene1, bundle = retrace_pair(kind, case, 2048)
+    a0, sol = oracle.trace(scene0, bundle, 20, threads=16, keep=True)
+    a1, sol1 = oracle.trace(scene1, bundle, 20, threads=16, keep=True, prev=sol)
+    a2 = oracle.trace(scene0, bundle, 20, threads=16, prev=sol1)
+    g0, gs0 = _engine_solve(scene0, bundle, 20)
+    compare(g0, a0, rtol, f"{kind}/{case} first solve")
+    g1, gs1 = _engine_solve(scene1, bundle, 20, gs0)
+    compare(g1, a1, rtol, f"{kind}/{case} retrace")
+    g1b, gs1b = _engine_solve(scene1, bundle, 20, gs0)  # the previous solution is not consumed
+    compare(g1b, g1, 0.0, f"{kind}/{case} retrace twice from the same solution")
+    g2, gs2 = _engine_solve(scene0, bundle, 20, gs1)
+    compare(g2, a2, rtol, f"{kind}/{case} retrace back")
+    for s in (gs0, gs1, gs1b, gs2):
+        s.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r_max", [1, 2, 3, 8])
+def test_gpu_retrace_r_max(oracle, r_max):
+    scene0, scene1, bundle = retrace_pair("ray", "shift_train", 512)
+    a0, sol = oracle.trace(scene0, bundle, 20, threads=16, keep=True)
+    a1 = oracle.trace(scene1, bundle, r_max, threads=16, prev=sol)
+    g0, gs0 = _engine_solve(scene0, bundle, 20)
+    g1, gs1 = _engine_solve(scene1, bundle, r_max, gs0)
+    compare(g1, a1, 0.0, f"r_max={r_max}")
+
+
+@pytest.mark.gpu
+def test_gpu_retrace_kats_through_the_host_mirror():
+    """The reference's plate-splitter retrace KAT (runtests.jl:2568-2591) through solve_system on the engine."""
+    N0 = 1.5
+    pbs = bmo.RectangularPlateBeamsplitter(36 * mm, 25 * mm, 1 * mm, lambda n: N0)
+    system = bmo.System([pbs])
+    beam = bmo.Beam([0, -50 * mm, 0], [0, 1, 0], 1e-6)
+    bmo.zrotate3d(pbs, math.radians(45))
+    bmo.solve_system(system, beam)
+    assert (len(beam.rays), len(beam.children[0].rays), len(beam.children[1].rays)) == (1, 2, 1)
+    bmo.zrotate3d(pbs, math.pi)
+    bmo.solve_system(system, beam)
+    p, t, r = beam.rays, beam.children[0].rays, beam.children[1].rays
+    assert (len(p), len(t), len(r)) == (2, 1, 2)
+    assert [x.n for x in p] == [1, N0] and [x.n for x in t] == [1] and [x.n for x in r] == [N0, 1]
+    assert approx(p[0].dir, t[-1].dir) and approx(r[-1].dir, [1, 0, 0])
+    bmo.release(beam)
+
+
+@pytest.mark.gpu
+def test_gpu_retrace_rejects_mismatched_batch():
+    scene0, scene1, bundle = retrace_pair("ray", "tilt_splitter", 64)
+    g0, gs0 = _engine_solve(scene0, bundle, 20)
+    with pytest.raises(RuntimeError):
+        _engine_solve(scene1, scenes.c2_bundle(32), 20, gs0)
