@@ -166,6 +166,7 @@ def load_engine():
     lib.bmo_retrace.argtypes = [vp, C.POINTER(RayBatch), vp, C.POINTER(TraceOpts), C.POINTER(vp)]
     lib.bmo_retrace_device.argtypes = [vp, vp, vp, C.POINTER(TraceOpts), C.POINTER(vp)]
     dp = C.POINTER(C.c_double)
+    lib.bmo_photodetector_field.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp]
     lib.bmo_psf_intensity.argtypes = [C.c_void_p, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp, dp]
     _engine = lib
     return lib

@@ -136,6 +136,9 @@ class GaussianBeamlet:
     def length(self):
         return self.chief.length()
 
+    def optical_path_length(self):  # Gaussian.jl:102
+        return self.chief.optical_path_length()
+
 
 def point_on_beam(beam, t):
     """Beam.jl:177-205: point at geometric distance t along the beam (parents included) and its 1-based segment index."""

@@ -13,7 +13,7 @@ from . import shapes as sh
 
 # object kinds (include/bmo.h enum bmo_object_kind)
 (O_MIRROR, O_REFRACTIVE, O_DOUBLET, O_THIN_BS, O_PLATE_BS, O_CUBE_BS, O_SPOT, O_PSF, O_INTERSECTABLE, O_NONINTERACTABLE,
- O_POLARIZER) = range(11)
+ O_POLARIZER, O_PHOTODETECTOR) = range(12)
 
 
 # ------------------------------------------------------------------ refractive indices
@@ -394,6 +394,37 @@ class PSFDetector(AbstractObject):  # Detectors/PSFDetector.jl:44-68
         o = self.orientation()
         fn = _intensity_fn or (lambda *a: abi.psf_intensity(*a, device=device)[0])
         return xs, zs, fn(self.data, self.position(), o[:, 0], o[:, 2], xs, zs)
+
+
+class Photodetector(AbstractObject):  # Detectors/Photodetector.jl:31-55
+    """Flat square detector whose complex field `field[i, j]` (local x = pd.x[i], local y = pd.y[j]) is the superposition of all
+    GaussianBeamlets that hit it (Photodetector.jl:69-107).  The trace records the hits; solve_system adds their field with the
+    engine's bmo_photodetector_field right after the solve, so `field` reads like the reference's after solve_system!."""
+    kind = O_PHOTODETECTOR
+
+    def __init__(self, width, n):
+        shape = sh.QuadraticFlatMesh(width)
+        super().__init__(shape)
+        sz = float(np.max(shape.vertices))
+        self.x = la.linrange(-sz, sz, n)
+        self.y = la.linrange(-sz, sz, n)
+        self.field = np.zeros((n, n), dtype=np.complex128)
+
+    def empty(self):  # empty!(pd) Photodetector.jl:119
+        self.field[...] = 0
+
+    def resolution(self, n):  # photodetector_resolution! Photodetector.jl:126-131
+        self.x = la.linrange(self.x[0], self.x[-1], n)
+        self.y = la.linrange(self.y[0], self.y[-1], n)
+        self.field = np.zeros((n, n), dtype=np.complex128)
+
+    def intensity(self):  # intensity.(pd.field), OpticUtils.jl:108
+        return (self.field.real ** 2 + self.field.imag ** 2) / (2 * la.Z_vacuum)
+
+    def optical_power(self):  # trapz((pd.x, pd.y), intensity(pd)) Photodetector.jl:116 (Trapz.jl: trapezoid rule along x, then y)
+        I = self.intensity()
+        inner = np.sum((I[1:, :] + I[:-1, :]) * np.diff(self.x)[:, None], axis=0) / 2
+        return float(np.sum((inner[1:] + inner[:-1]) * np.diff(self.y)) / 2)
 
 
 class IntersectableObject(AbstractObject):  # Intersectable.jl:10-15

@@ -1233,7 +1233,8 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
         if ((o.kind == BMO_OBJ_REFRACTIVE || o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_PLATE_BS || o.kind == BMO_OBJ_CUBE_BS) && o.medium[0] < 0)
             return fail(BMO_ERR_INVALID, "refractive object without medium");
         if ((o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_CUBE_BS) && o.medium[1] < 0) return fail(BMO_ERR_INVALID, "missing second medium");
-        if ((o.kind == BMO_OBJ_SPOTDETECTOR || o.kind == BMO_OBJ_PSFDETECTOR) && (o.detector < 0 || o.detector >= d->n_detectors))
+        if ((o.kind == BMO_OBJ_SPOTDETECTOR || o.kind == BMO_OBJ_PSFDETECTOR || o.kind == BMO_OBJ_PHOTODETECTOR) &&
+            (o.detector < 0 || o.detector >= d->n_detectors))
             return fail(BMO_ERR_INVALID, "detector slot out of bounds");
         if (o.kind == BMO_OBJ_THIN_BS || o.kind == BMO_OBJ_PLATE_BS || o.kind == BMO_OBJ_CUBE_BS) has_split = true;
     }

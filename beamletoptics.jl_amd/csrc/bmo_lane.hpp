@@ -1270,6 +1270,41 @@ BMO_HD double gauss_w0_at(const GaussIn& g, double t_total, double temp) {
 }
 
 
+// gauss_parameters(gauss, z; hint = (p0, index)) Gaussian.jl:298-353 for the chief / waist / divergence rays of segment `index`
+// and the point p0 on the chief ray: w, R (curvature 1/r), psi (Gouy phase, -atan convention), w0 (local waist).
+BMO_HD void gauss_parameters_at(const RayS& c, const RayS& wr, const RayS& dr, const d3& p0, double lambda, double& w, double& R, double& psi,
+                                double& w0) {
+    double y_d, m_d, y_w, m_w;
+    {
+        double il = line_plane_distance3d(p0, c.dir, dr.pos, dr.dir);
+        d3 y0{dr.pos.x + il * dr.dir.x - p0.x, dr.pos.y + il * dr.dir.y - p0.y, dr.pos.z + il * dr.dir.z - p0.z};
+        y_d = norm3(y0);
+        y0 = {y0.x / y_d, y0.y / y_d, y0.z / y_d};
+        m_d = tan(3.141592653589793 / 2 - angle3d(y0, dr.dir));
+    }
+    {
+        double il = line_plane_distance3d(p0, c.dir, wr.pos, wr.dir);
+        d3 y0{wr.pos.x + il * wr.dir.x - p0.x, wr.pos.y + il * wr.dir.y - p0.y, wr.pos.z + il * wr.dir.z - p0.z};
+        y_w = norm3(y0);
+        y0 = {y0.x / y_w, y0.y / y_w, y0.z / y_w};
+        m_w = tan(3.141592653589793 / 2 - angle3d(y0, wr.dir));
+    }
+    const double n = c.n;
+    double H = fabs(n * (y_w * m_d - y_d * m_w));
+    if (!isapprox(H, lambda / 3.141592653589793, 1e-6)) H = lambda / 3.141592653589793;
+    const double E_kt = y_d * m_d + y_w * m_w;
+    const double F_kt = sqrt(m_d * m_d + m_w * m_w);
+    w = sqrt(y_d * y_d + y_w * y_w);
+    R = E_kt / (w * w);
+    const double zz = E_kt / (F_kt * F_kt);
+    psi = -atan2(1.0, sqrt(1 / (R * zz) - 1));
+    w0 = H / (n * F_kt);
+    if (isnan_(R)) R = 0;
+    if (isnan_(psi)) psi = 0;
+    if (isnan_(w0)) w0 = w;
+    if (R < 0) psi = -psi;
+}
+
 // by-value selection of one of three rays / hits with scalar selects (a reference select `r == 0 ? g.c : ...` forces the
 // structs into scratch memory: the first Gaussian kernel spilled 1.8 KB per lane)
 BMO_HD double sel3(int r, double a, double b, double c) { return r == 0 ? a : (r == 1 ? b : c); }
@@ -1344,6 +1379,20 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
     }
     const int32_t oid = o.Xc.obj;
     CObject& ob = S.objects[oid];
+    if (ob.kind == BMO_OBJ_PHOTODETECTOR) {  // Photodetector.jl:69-107: record the hit (field read-out is a separate pass), stop
+        o.det_slot = ob.detector;
+        for (int c = 0; c < 27; ++c) o.det[c] = 0.0;
+        o.det[0] = fabs(dot3(g.c.dir, o.Xc.n));  // proj = abs(dot(d0, normal3d(ray_int)))
+        o.n_det = 3;
+        o.status |= BMO_NODE_DETECTED;
+        o.lenA = g.lenA + o.Xc.t;
+        o.lenB = g.lenB + o.Xc.t;
+        o.oplC = g.oplC + o.Xc.t * g.c.n;
+        o.oplW = g.oplW + o.Xw.t * g.w.n;
+        o.oplD = g.oplD + o.Xd.t * g.d.n;
+        o.outcome = OUT_STOP;
+        return;
+    }
     const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && o.Xc.shape == ob.shape[1]) ||
                          (ob.kind == BMO_OBJ_CUBE_BS && o.Xc.shape == ob.shape[2]);
     // every sub-beam interacts with the object found by the CHIEF ray (System.jl:306-309, Gaussian.jl:124-135)

@@ -124,7 +124,7 @@ class CompiledScene:
                 rec.medium[0] = medium_of(o.front.n)
                 rec.medium[1] = medium_of(o.back.n)
                 rec.reflectance, rec.transmittance = o.coating.reflectance, o.coating.transmittance
-            elif o.kind in (cp.O_SPOT, cp.O_PSF):
+            elif o.kind in (cp.O_SPOT, cp.O_PSF, cp.O_PHOTODETECTOR):
                 rec.detector = len(self.detectors)
                 self.detectors.append(o)
             elif o.kind == cp.O_POLARIZER:
@@ -355,6 +355,21 @@ class EngineSolution:
         except Exception:
             pass
 
+    def photodetector_field(self, slot, position, orientation, xs, ys, field):
+        """bmo_photodetector_field: adds the field of the beamlets recorded on detector `slot` to `field[i, j]` (in place)."""
+        dp = C.POINTER(C.c_double)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (position, np.asarray(orientation).reshape(9), xs, ys)]
+        nx, ny = len(a[2]), len(a[3])
+        buf = np.zeros(2 * nx * ny)  # (i, j) at [i + nx*j]
+        ft = np.ascontiguousarray(field.T)
+        buf[0::2], buf[1::2] = ft.real.reshape(-1), ft.imag.reshape(-1)
+        ms = C.c_double()
+        abi.check(self.lib, self.lib.bmo_photodetector_field(self.handle, int(slot), a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp),
+                                                             a[2].ctypes.data_as(dp), a[3].ctypes.data_as(dp), nx, ny, buf.ctypes.data_as(dp),
+                                                             C.byref(ms)), "bmo_photodetector_field")
+        field[...] = (buf[0::2] + 1j * buf[1::2]).reshape(ny, nx).T
+        return ms.value
+
 
 def _engine_solve(scene, bundle, r_max, prev, device=0):
     """One solve on the HIP engine: bmo_trace, or bmo_retrace when `prev` (an EngineSolution) is given."""
@@ -417,6 +432,9 @@ def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=Non
         hits = res.detector_hits(slot)
         if det.kind == cp.O_SPOT:
             det.data = np.concatenate([det.data, hits[:, 0:2]], axis=0)
+        elif det.kind == cp.O_PHOTODETECTOR:
+            if len(hits):  # pd.field[i, j] += electric_field(gauss, r, z) * sqrt(proj) for every recorded beamlet (Photodetector.jl:85-105)
+                sol.photodetector_field(slot, det.position(), det.orientation(), det.x, det.y, det.field)
         else:
             det.data = np.concatenate([det.data, hits], axis=0)
     return res

@@ -123,6 +123,10 @@ enum bmo_object_kind {
     BMO_OBJ_INTERSECTABLE = 8,   /* Intersectable.jl:15                                           */
     BMO_OBJ_NONINTERACTABLE = 9, /* NonInteractable.jl:19-20                                      */
     BMO_OBJ_POLARIZER = 10,      /* PolarizationFilter.jl:31-48                                   */
+    BMO_OBJ_PHOTODETECTOR = 11,  /* Detectors/Photodetector.jl:57-107: a GaussianBeamlet that hits it stops and is
+                                    recorded in the detector slot (3 hit rows per beamlet, row 0 = {proj, 0...});
+                                    the complex field is read out with bmo_photodetector_field.  Ray / PolarizedRay
+                                    beams stop without a record (Photodetector.jl:57-60 warns)              */
     BMO_OBJ_KIND_COUNT
 };
 
@@ -316,6 +320,27 @@ int bmo_retrace_device(bmo_scene* scene, bmo_device_batch* batch, bmo_trace_resu
 int bmo_psf_intensity(const double* hits, int64_t n_hits, int32_t hits_on_device, const double origin[3], const double e1[3],
                       const double e2[3], const double* xs, const double* zs, int32_t n, int32_t device, double* out_intensity,
                       double* out_field, double* kernel_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Photodetector field: interact3d(::Photodetector, ::GaussianBeamlet, ray_id) —
+ * src/OpticalComponents/Detectors/Photodetector.jl:69-107 with electric_field(gauss, r, z) src/Gaussian.jl:381-392,
+ * gauss_parameters :298-353, point_on_beam src/Beam.jl:177-205, electric_field(r, z, ...) src/Utils/OpticUtils.jl:87-89.
+ *
+ * For every beamlet of `res` recorded on detector slot `detector` (reference order) and every grid point (i, j):
+ *   p1 = position + xs[i]*orientation[:,1] + ys[j]*orientation[:,3]      (written out per component like the reference)
+ *   l1 = dot(p1 - p0, d0);  r = |p1 - (p0 + l1*d0)|;  z = l0 + l1       (p0, d0: last chief ray; l0 = length up to it)
+ *   field(i,j) += electric_field(gauss, r, z) * sqrt(proj)
+ * The reference does this inside solve_system!; here the trace only records the hit and this call evaluates the sum on the
+ * GPU from the segment log still resident in `res` (any segment of the beamlet may be selected by point_on_beam).
+ *
+ * position / orientation : the detector's pose (orientation row-major 3x3, columns = local axes) at solve time.
+ * xs[nx], ys[ny]         : local sample coordinates (the reference's LinRange pd.x, pd.y).
+ * field_inout            : host, nx*ny complex values as (re, im) pairs, element (i,j) at [i + nx*j]; contributions are ADDED
+ *                          (the reference accumulates until empty!(pd)).
+ * The sum over beamlets is evaluated in a fixed blocked order: parity with the reference is to FP64 re-association
+ * tolerance, not bit-exact.                                                                                          */
+int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, const double position[3], const double orientation[9], const double* xs,
+                            const double* ys, int32_t nx, int32_t ny, double* field_inout, double* kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -1244,6 +1244,14 @@ GInter interact_gauss(Ctx& C, Node& g, int id /*1-based*/) {
         return true;
     };
     switch (o.kind) {
+        case BMO_OBJ_PHOTODETECTOR: {  // Photodetector.jl:69-107: the field is accumulated by photodetector_field() below; the hit is recorded
+            double d9[9] = {std::fabs(dot(rc.dir, rc.isect.n)), 0, 0, 0, 0, 0, 0, 0, 0}, z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            push_det(C, o.detector, d9);
+            push_det(C, o.detector, z9);
+            push_det(C, o.detector, z9);
+            g.status |= BMO_NODE_DETECTED;
+            return GInter{};
+        }
         case BMO_OBJ_THIN_BS: split(1.0, 1.0, false, false); return GInter{};
         case BMO_OBJ_PLATE_BS: {
             if (rc.isect.shape == o.shape[0]) {
@@ -1460,6 +1468,7 @@ struct Result {
     std::vector<double> det_data;
     std::vector<std::unique_ptr<Node>> roots;  // the solved beam trees (input of a later bmo_cpu_retrace)
     int kind = 0;
+    std::vector<bmo_object> objects;           // object table the solution was solved with (photodetector read-out)
 };
 
 struct RootOut {
@@ -1653,6 +1662,7 @@ static int finalize(const Scene& S, const bmo_ray_batch* in, std::vector<RootOut
     const int64_t n = in->n;
     auto* R = new Result();
     R->kind = in->kind;
+    R->objects = S.objects;
     int rp = rec_planes_for(in->kind);
     size_t nnodes = 0, nrec = 0;
     for (auto& o : outs) {
@@ -1853,6 +1863,61 @@ void bmo_cpu_global_E0(const double* in_dir, const double* out_dir, const double
         out6[2 * i] = o[i].re;
         out6[2 * i + 1] = o[i].im;
     }
+}
+
+// interact3d(::Photodetector, gauss, ray_id) Photodetector.jl:69-107 for every beamlet of a solved batch that ended on the
+// photodetector of slot `detector`, in solve order (bundle order x BFS order), added to field (nx*ny complex, (i,j) at [i + nx*j]).
+// electric_field(gauss, r, z) Gaussian.jl:381-392; electric_field(r, z, E0, w0, w, k, psi, R) OpticUtils.jl:87-89.
+int bmo_cpu_photodetector_field(void* handle, int detector, const double* position, const double* orientation, const double* xs, const double* ys,
+                                int nx, int ny, double* field) {
+    const Result* R = static_cast<const Result*>(handle);
+    if (!R || R->kind != BMO_BEAM_GAUSSIAN) return BMO_OK;
+    // T = transpose(orientation): T[k,1] = orientation[1,k], T[k,3] = orientation[3,k]  (orientation row-major)
+    const double ox[3] = {orientation[0], orientation[1], orientation[2]}, oy[3] = {orientation[6], orientation[7], orientation[8]};
+    for (const auto& root : R->roots) {
+        std::deque<const Node*> queue{root.get()};
+        while (!queue.empty()) {
+            const Node* g = queue.front();
+            queue.pop_front();
+            for (const auto& ch : g->children) queue.push_back(ch.get());
+            const Ray& ray = g->chief.rays.back();
+            if (!ray.has_isect) continue;
+            const bmo_object& o = R->objects[(size_t)ray.isect.obj];
+            if (o.kind != BMO_OBJ_PHOTODETECTOR || o.detector != detector) continue;
+            const double len_g = len_beam(g->chief);
+            const double l0 = len_g - ray.isect.t;
+            const D3 p0 = ray.pos, d0 = ray.dir;
+            const double proj = std::fabs(dot(d0, ray.isect.n));
+            const double k = 2 * M_PI / g->lambda;
+            const double dl = opl_beam(g->chief) - len_g;
+            const double ref_phi = dl / g->lambda * (2 * M_PI);
+            for (int j = 0; j < ny; ++j) {
+                const double y = ys[j];
+                for (int i = 0; i < nx; ++i) {
+                    const double x = xs[i];
+                    const D3 p1{ox[0] * x + oy[0] * y + position[0], ox[1] * x + oy[1] * y + position[1], ox[2] * x + oy[2] * y + position[2]};
+                    const double l1 = dot(p1 - p0, d0);
+                    const D3 p2{p0.x + l1 * d0.x, p0.y + l1 * d0.y, p0.z + l1 * d0.z};
+                    const double r = norm(p1 - p2);
+                    const double z = l0 + l1;
+                    double gp[4];
+                    gauss_parameters(*g, z, gp);  // hint = point_on_beam(gauss, z), the default
+                    const double w = gp[0], Rc = gp[1], psi = gp[2], w0 = gp[3];
+                    Cx E = g->E0 * (g->w0 / w0);
+                    E = E * w0;
+                    E = Cx{E.re / w, E.im / w};
+                    E = E * std::exp(-(r * r) / (w * w));
+                    const double ph = k * z + psi + (k * (r * r) * Rc) / 2;
+                    E = E * Cx{std::cos(ph), std::sin(ph)};
+                    E = E * Cx{std::cos(ref_phi), std::sin(ref_phi)};
+                    E = E * std::sqrt(proj);
+                    field[2 * ((size_t)i + (size_t)nx * j)] += E.re;
+                    field[2 * ((size_t)i + (size_t)nx * j) + 1] += E.im;
+                }
+            }
+        }
+    }
+    return BMO_OK;
 }
 
 // intensity(psf::PSFDetector) PSFDetector.jl:190-237 — the coherent sum over recorded hits, evaluated per grid point in

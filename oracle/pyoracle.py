@@ -44,6 +44,7 @@ def lib():
         L.bmo_cpu_refraction3d.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
         L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
+        L.bmo_cpu_photodetector_field.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp]
         L.bmo_cpu_psf_intensity.argtypes = [dp, C.c_longlong, dp, dp, dp, dp, dp, C.c_int, dp, dp]
         L.bmo_cpu_psf_intensity.restype = None
         _lib = L
@@ -71,6 +72,19 @@ class Solution:
             self.free()
         except Exception:
             pass
+
+    def photodetector_field(self, slot, position, orientation, xs, ys, field):
+        """Photodetector.jl:69-107 on the CPU for the beamlets of this solution recorded on detector `slot` (adds to field[i, j])."""
+        dp = C.POINTER(C.c_double)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (position, np.asarray(orientation).reshape(9), xs, ys)]
+        nx, ny = len(a[2]), len(a[3])
+        buf = np.zeros(2 * nx * ny)
+        ft = np.ascontiguousarray(field.T)
+        buf[0::2], buf[1::2] = ft.real.reshape(-1), ft.imag.reshape(-1)
+        lib().bmo_cpu_photodetector_field(self.handle, int(slot), a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp),
+                                          a[3].ctypes.data_as(dp), nx, ny, buf.ctypes.data_as(dp))
+        field[...] = (buf[0::2] + 1j * buf[1::2]).reshape(ny, nx).T
+        return 0.0
 
 
 def trace(scene, bundle, r_max=100, threads=1, keep=False, prev=None):
