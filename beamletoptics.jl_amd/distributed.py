@@ -37,3 +37,13 @@ def all_gather_hits(local_hits, group=None):
     dist.all_gather(outs, buf, group=group)
     hits = torch.cat([outs[r][: int(counts[r])] for r in range(world)], dim=0)
     return hits, counts
+
+
+def all_reduce_field(field, group=None):
+    """Sum of the per-rank Photodetector fields: every rank accumulates the field of ITS shard of beamlets with
+    bmo_photodetector_field; the detector's field is their sum, one all-reduce of the nx x ny complex grid (viewed as float64
+    pairs; RCCL ring all-reduce over xGMI for `nccl`).  Summation order differs from the single-process solve, so the result
+    agrees with it to FP64 re-association tolerance.  `field`: complex128 tensor [nx, ny]; reduced in place and returned."""
+    buf = torch.view_as_real(field)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return field

@@ -241,6 +241,13 @@ class Engine:
         abi.check(self.lib, self.lib.bmo_trace_device(self.handle, dev_batch, C.byref(o), C.byref(res)), "bmo_trace_device")
         return res
 
+    def retrace_device(self, dev_batch, prev, r_max=100):
+        """bmo_retrace_device: re-solve the batch of `prev` (a result handle) against this engine's scene."""
+        res = C.c_void_p()
+        o = self.opts(r_max)
+        abi.check(self.lib, self.lib.bmo_retrace_device(self.handle, dev_batch, prev, C.byref(o), C.byref(res)), "bmo_retrace_device")
+        return res
+
     def result_timing(self, res):
         ms, tot, nl = C.c_double(), C.c_double(), C.c_int32()
         abi.check(self.lib, self.lib.bmo_result_timing(res, C.byref(ms), C.byref(tot), C.byref(nl)), "bmo_result_timing")

@@ -75,3 +75,40 @@ def test_shard_bounds_cover():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _pd_worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bmo_amd as bmo
+    import pyoracle
+    from bmo_amd import distributed as bd
+    from test_photodetector import pd_scene
+
+    system, pd, full = pd_scene(n)
+    lo, hi = bd.shard_bounds(n, rank, world)
+    shard = bmo.RayBundle(full.kind, full.planes[:, lo:hi])
+    scene = bmo.CompiledScene(system, full.lambdas)
+    res, sol = pyoracle.trace(scene, shard, 20, threads=2, keep=True)
+    f = np.zeros((len(pd.x), len(pd.y)), dtype=np.complex128)
+    sol.photodetector_field(0, pd.position(), pd.orientation(), pd.x, pd.y, f)
+    total = bd.all_reduce_field(torch.from_numpy(f.copy())).numpy()  # the exchange step of the Photodetector path (§8e)
+    if rank == 0:
+        ref, rsol = pyoracle.trace(scene, full, 20, threads=2, keep=True)
+        fr = np.zeros_like(f)
+        rsol.photodetector_field(0, pd.position(), pd.orientation(), pd.x, pd.y, fr)
+        assert np.abs(total - fr).max() <= 1e-12 * np.abs(fr).max()
+        assert np.abs(fr).max() > 0
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_photodetector_field_all_reduce(tmp_path):
+    world = 2
+    mp.spawn(_pd_worker, args=(world, _free_port(), 48, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
