@@ -125,7 +125,9 @@ struct Chunk {
 };
 
 struct Counters {  // device-resident, one per trace
-    unsigned long long next_count;
+    // records written to the next chunk.  Two slots: step s accumulates into slot s & 1 and clears the other one for step s + 1
+    // (the host has read it before launching step s), so no host->device reset sits between two launches.
+    unsigned long long next_count[2];
     unsigned long long node_count;
     unsigned long long calls;
     unsigned long long overflow;
@@ -166,6 +168,7 @@ struct StepParams {
     unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
     NodeArrays nodes;
     int32_t r_max;
+    int32_t parity;   // step & 1: which next_count slot this launch fills
     OldSolution old;  // RETR kernels only
 };
 
@@ -220,7 +223,7 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
         const uint32_t ts = w32[0] + w32[1] + w32[2] + w32[3], tp = w32[4] + w32[5] + w32[6] + w32[7];
         const uint32_t tc = w32[8] + w32[9] + w32[10] + w32[11];
         unsigned long long b = 0, nb = 0;
-        if (ts + tp) b = atomicAdd(&P.ctr->next_count, (unsigned long long)(ts + 2 * tp));
+        if (ts + tp) b = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(ts + 2 * tp));
         if (tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
         if (tc) atomicAdd(&P.call_shards[(blockIdx.x & 63u) * 16u], (unsigned long long)tc);  // sharded, no return value
         w64[0] = b;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
     char* scratch = lds + (LDS ? P.blob_bytes : 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count, cap = P.cur.cap;
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
     char* scratch = lds + (LDS ? P.blob_bytes : 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count, cap = P.cur.cap;
     const bool valid = j < m;
@@ -885,26 +890,28 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     struct DevCtx {
         hipStream_t stream = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        Counters* pinned = nullptr;
+        std::vector<hipEvent_t> step_ev;
     };
     static std::mutex ctx_mu;
-    static std::vector<std::pair<int, DevCtx>> ctxs;
-    DevCtx ctx;
+    static std::vector<std::pair<int, std::unique_ptr<DevCtx>>> ctxs;
+    DevCtx* ctxp = nullptr;
     {
         std::lock_guard<std::mutex> lk(ctx_mu);
-        bool found = false;
         for (auto& c : ctxs)
-            if (c.first == device) {
-                ctx = c.second;
-                found = true;
-            }
-        if (!found) {
-            HIP_TRY(hipStreamCreate(&ctx.stream));
-            for (int q = 0; q < 4; ++q) HIP_TRY(hipEventCreate(&ctx.ev[q]));
-            ctxs.emplace_back(device, ctx);
+            if (c.first == device) ctxp = c.second.get();
+        if (!ctxp) {
+            auto nc = std::make_unique<DevCtx>();
+            HIP_TRY(hipStreamCreate(&nc->stream));
+            for (int q = 0; q < 4; ++q) HIP_TRY(hipEventCreate(&nc->ev[q]));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&nc->pinned), sizeof(Counters), hipHostMallocDefault));
+            ctxp = nc.get();
+            ctxs.emplace_back(device, std::move(nc));
         }
     }
+    DevCtx& ctx = *ctxp;
     hipStream_t stream = ctx.stream;
-    hipEvent_t ev_a = ctx.ev[0], ev_b = ctx.ev[1], ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
+    hipEvent_t ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
     HIP_TRY(hipEventRecord(ev_t0, stream));
 
     const int nsub = KIND == BMO_BEAM_GAUSSIAN ? 3 : 1;
@@ -998,8 +1005,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if ((rc = ctr_buf.alloc(sizeof(Counters))) || (rc = shard_buf.alloc(64 * 128))) return rc;
     HIP_TRY(hipMemsetAsync(shard_buf.p, 0, 64 * 128, stream));
     Counters* d_ctr = static_cast<Counters*>(ctr_buf.p);
-    Counters h_ctr{0, (unsigned long long)n, 0, 0};
-    HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, stream));
+    Counters* h_ctr_p = ctx.pinned;  // pinned: the per-step read-back does not go through a staging copy
+    Counters& h_ctr = *h_ctr_p;
+    h_ctr = Counters{{0, 0}, (unsigned long long)n, 0, 0};
+    HIP_TRY(hipMemcpyAsync(d_ctr, h_ctr_p, sizeof h_ctr, hipMemcpyHostToDevice, stream));
 
     Chunk cur;
     if ((rc = new_chunk(n, cur))) return rc;
@@ -1072,27 +1081,36 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
         P.nodes = node_arrays();
         P.r_max = opts->r_max;
+        P.parity = steps & 1;
         P.old = old_tab;
         DBG("step %d launching m=%lld", steps, (long long)m);
-        HIP_TRY(hipEventRecord(ev_a, stream));
+        // launch timing: one event pair per step out of a cached pool, read after the loop (nothing but the counter read-back
+        // sits between two launches)
+        while ((int)ctxp->step_ev.size() < 2 * (steps + 1)) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctxp->step_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
         hipLaunchKernelGGL(kern, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
-        HIP_TRY(hipEventRecord(ev_b, stream));
-        HIP_TRY(hipMemcpyAsync(&h_ctr, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps + 1], stream));
+        HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ev_a, ev_b));
-        kernel_ms += ms;
-        DBG("step %d done %.3f ms next=%llu nodes=%llu calls=%llu", steps, ms, h_ctr.next_count, h_ctr.node_count, h_ctr.calls);
+        const unsigned long long produced = h_ctr.next_count[steps & 1];
+        DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
         R->chunks.push_back(cur);
-        shrink_last(nxt, (int64_t)h_ctr.next_count);
+        shrink_last(nxt, (int64_t)produced);
         n_nodes = (int64_t)h_ctr.node_count;
         cur = nxt;
-        // reset next_count for the following step
-        h_ctr.next_count = 0;
-        HIP_TRY(hipMemcpyAsync(d_ctr, &h_ctr, sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    }
+    for (int q = 0; q < steps; ++q) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctxp->step_ev[2 * q], ctxp->step_ev[2 * q + 1]));
+        kernel_ms += ms;
+        DBG("step %d kernel %.3f ms", q, ms);
     }
     lap("steps");
     R->n_nodes = n_nodes;

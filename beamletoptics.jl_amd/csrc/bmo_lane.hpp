@@ -40,6 +40,10 @@
 
 namespace bmo {
 
+#if defined(BMO_EMU_STATS)  // host-only instrumentation of the test emulator (tools/emu_stats.py)
+inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0;
+#endif
+
 // Scene tables can be addressed through the constant address space (scalar loads, operands in SGPRs) when the build
 // defines BMO_SCALAR_SCENE; otherwise they are plain (generic / LDS) pointers.
 #if defined(__HIPCC__) && defined(BMO_SCALAR_SCENE)
@@ -493,6 +497,9 @@ BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
 // the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
 template <bool ASPH>
 BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child) {
+#if defined(BMO_EMU_STATS)
+    ++g_emu_sdf_any;
+#endif
     const v3<double> pt{p.x, p.y, p.z};
     const bool uni = s.kind == BMO_SHAPE_UNION;
     const int nch = uni ? s.child_count : 1;
@@ -511,6 +518,9 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
             skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
         }
         if (!skip) {
+#if defined(BMO_EMU_STATS)
+            ++g_emu_sdf_leaf;
+#endif
             double v = sdf_simple<double, ASPH>(S, ch, pt);
             if (c == 0) {
                 best = v;

@@ -5,6 +5,7 @@
 // bounce-synchronous schedule as step_kernel, one "lane" at a time.  It is NOT a fallback: the
 // product package never loads it (see beamletoptics.jl_amd/abi.py: the engine is libbmo_hip.so only).
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -84,6 +85,10 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     unsigned long long calls = 0;
     int steps = 0;
     while (!cur.empty()) {
+#if defined(BMO_EMU_STATS)
+        const long a0 = g_emu_sdf_any, l0 = g_emu_sdf_leaf;
+        const size_t m0 = cur.size();
+#endif
         std::vector<Rec> surv, kids;
         for (Rec& r : cur) {
             StepOut o;
@@ -181,6 +186,10 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             }
         }
         all.insert(all.end(), cur.begin(), cur.end());
+#if defined(BMO_EMU_STATS)
+        fprintf(stderr, "step %2d records %6zu  union sdf evals/record %7.2f  leaf sdf evals/record %7.2f\n", steps, m0, double(g_emu_sdf_any - a0) / m0,
+                double(g_emu_sdf_leaf - l0) / m0);
+#endif
         cur = surv;
         cur.insert(cur.end(), kids.begin(), kids.end());
         steps += 1;
