@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
         if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
         } else {
-            X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hobj, hshape, calls, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+            // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
+            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, 256, 0};
+            X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hobj, hshape, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             if (X.shape < 0) {
                 status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
             } else {
@@ -483,7 +485,8 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;
         } else {
-            gauss_step<ASPH, RETR>(S, g, o, calls, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, 256, 0};
+            gauss_step<ASPH, RETR>(S, g, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
             else if (o.outcome == OUT_SPLIT) {
@@ -1042,7 +1045,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipGetLastError());
         DBG("init kernel done");
     }
-    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64;  // + block_alloc scratch
+    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)BMO_CC_MAX * 256 * 8;  // + block_alloc scratch + child cache columns
     void (*kern)(StepParams) = nullptr;
     const bool asph = scene->hdr.has_asphere != 0;
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {

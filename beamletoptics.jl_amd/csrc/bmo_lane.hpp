@@ -493,43 +493,82 @@ BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
     return a;
 }
 
+// Per-lane memory of the child values of ONE union along ONE march (device: a column of LDS, host emulator: a local array).
+// v[c * stride] holds a lower bound of child c's sdf at the point of the previous evaluation (-inf = unknown).
+constexpr int BMO_CC_MAX = 8;
+struct ChildCache {
+    double* v;
+    int stride;
+    int prev_best;  // arg-min child of the previous evaluation (evaluated first: it usually gives the tightest bound)
+};
+BMO_HD void child_cache_reset(ChildCache& cc) {
+    for (int c = 0; c < BMO_CC_MAX; ++c) cc.v[c * cc.stride] = -kinf();
+    cc.prev_best = 0;
+}
+
 // sdf(shape, p) for any SDF shape incl. UnionSDF (UnionSDF.jl:53-56, left-fold min) together with
 // the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
+//
+// Children that provably cannot be the minimum are not evaluated (result-preserving, DESIGN.md "union child skip"):
+//  (1) bounding sphere: outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6;
+//  (2) Lipschitz memory: every exact child sdf is 1-Lipschitz, so after the march moved the point by `moved` the child's value is
+//      >= (its value, or lower bound, at the previous point) - moved.
+// A child whose lower bound exceeds max(bound, 0) by a margin is strictly greater than the final minimum (bound >= final minimum),
+// so it changes neither the fold min nor the first-minimum index.  Evaluation order: the previous arg-min child first, then index
+// order; min is exact and the arg-min rule below is written order-independently (lowest index among equal minima, -0.0 < +0.0
+// like isless), so the result equals the reference's left fold.
 template <bool ASPH>
-BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child) {
+BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child, ChildCache& cc, double moved) {
 #if defined(BMO_EMU_STATS)
     ++g_emu_sdf_any;
 #endif
     const v3<double> pt{p.x, p.y, p.z};
     const bool uni = s.kind == BMO_SHAPE_UNION;
     const int nch = uni ? s.child_count : 1;
-    double best = 0.0;
+    double best = kinf();
     best_child = 0;
+    bool have = false;
+    const int first = (uni && cc.prev_best < nch) ? cc.prev_best : 0;
+    const double slack = moved * (1.0 + 1e-9) + 1e-12;  // |dir| is 1 only to rounding
     BMO_NOUNROLL
-    for (int c = 0; c < nch; ++c) {
+    for (int q = 0; q < nch; ++q) {
+        const int c = q == 0 ? first : (q <= first ? q - 1 : q);
         CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[S.children[s.child_begin + BMO_UNIFORM(c)]] : &s);
         bool skip = false;
-        if (c > 0 && ch.bs_radius >= 0.0 && !(ch.flags & BMO_SHAPE_FLAG_INEXACT)) {
-            // Child skip (result-preserving): outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6.
-            // If p is outside that sphere by more than max(best, 0), the child's value is > best, so it can change neither
-            // the left-fold min (UnionSDF.jl:53-56) nor the first-minimum index (UnionSDF.jl:86-91).
-            const double ox = p.x - ch.bs_center[0], oy = p.y - ch.bs_center[1], oz = p.z - ch.bs_center[2];
-            const double lim = ch.bs_radius + (best > 0.0 ? best : 0.0);
-            skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
+        double lb = -kinf();
+        if (have && !(ch.flags & BMO_SHAPE_FLAG_INEXACT)) {
+            const double bound = best > 0.0 ? best : 0.0;
+            if (ch.bs_radius >= 0.0) {
+                const double ox = p.x - ch.bs_center[0], oy = p.y - ch.bs_center[1], oz = p.z - ch.bs_center[2];
+                const double lim = ch.bs_radius + bound;
+                skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
+            }
+            if (!skip && c < BMO_CC_MAX) {
+                lb = cc.v[c * cc.stride] - slack;
+                skip = lb > bound + 1e-12;
+            }
         }
         if (!skip) {
 #if defined(BMO_EMU_STATS)
             ++g_emu_sdf_leaf;
 #endif
-            double v = sdf_simple<double, ASPH>(S, ch, pt);
-            if (c == 0) {
+            const double v = sdf_simple<double, ASPH>(S, ch, pt);
+            if (uni && c < BMO_CC_MAX) cc.v[c * cc.stride] = v;
+            if (!have) {
                 best = v;
+                best_child = c;
+                have = true;
             } else {
-                if ((v < best) || (v == best && sgn(v) && !sgn(best))) best_child = c;
+                const bool less = (v < best) || (v == best && sgn(v) && !sgn(best));
+                const bool same = (v == best) && (sgn(v) == sgn(best));
+                if (less || (same && c < best_child)) best_child = c;
                 best = jmin(best, v);
             }
+        } else if (uni && c < BMO_CC_MAX) {
+            cc.v[c * cc.stride] = lb;  // still a valid lower bound at this point (-inf when only the sphere test skipped it)
         }
     }
+    if (uni) cc.prev_best = best_child;
     return best;
 }
 
@@ -616,7 +655,7 @@ BMO_HD double moeller_trumbore(CDouble* f, const d3& pos, const d3& dir, double 
 //   sub-tolerance step (>= -1e-8*dist for these 1-Lipschitz SDFs), so with the caller's 1e-6 margin the
 //   pruned shape is provably a loser; results are unchanged (DESIGN.md "nearest-hit prune").
 template <bool ASPH>
-BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit) {
+BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit, ChildCache& cc) {
     CShape& s = S.shapes[sid];
     Hit h = no_hit();
     {
@@ -651,15 +690,19 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
     int i_out = 1, i_in = 1;
     bool back = false;
+    child_cache_reset(cc);
     for (;;) {
+        double moved = 0.0;  // how far this iteration moved the evaluation point (Lipschitz memory of the union children)
         if (phase == INSIDE) {
             pos = axpy3(pos, S.eps_ins, dir);
             t_in += S.eps_ins;
+            moved = S.eps_ins;
         } else if (phase == OUTSIDE) {
             pos = axpy3(pos, dist, dir);
+            moved = fabs(dist);
         }
         int32_t bc;
-        const double d = sdf_any<ASPH>(S, s, pos, bc);
+        const double d = sdf_any<ASPH>(S, s, pos, bc, cc, moved);
         bool want_normal = false;
         if (phase == CLASSIFY) {
             if (d > S.eps_srf) {
@@ -729,7 +772,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
 // (intersect3d(object(_intersection), ray)); a probe miss is the reference's cleanup path, after which solve_leaf!
 // traces the same ray on WITHOUT a hint (System.jl:130-133) if `fresh_allowed` (length(rays) < r_max).
 template <bool ASPH, bool RETR = false>
-BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls,
+BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls, ChildCache& cc,
                         bool probe = false, int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     Hit X = no_hit();
     bool done = false;
@@ -795,12 +838,12 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
                     int32_t u_cmp = u;
                     asm volatile("" : "+s"(u_cmp));  // keeps the optimiser from substituting the per-lane id back for `u`
                     if (u_cmp == sid) {
-                        tmp = intersect_shape<ASPH>(S, u, pos, dir, lim);
+                        tmp = intersect_shape<ASPH>(S, u, pos, dir, lim, cc);
                         pending = false;
                     }
                 }
 #else
-                Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim);
+                Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim, cc);
 #endif
                 if (tmp.shape < 0) continue;
                 if (res.shape < 0) {
@@ -1339,7 +1382,7 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
 // hit the same shape (:377-392).  Otherwise the beamlet is cut here and trace_system! goes on from these rays without a
 // hint (System.jl:274-318) when `fresh_allowed`.
 template <bool ASPH, bool RETR = false>
-BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, bool probe = false, int32_t probe_obj = -1,
+BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
                        bool fresh_allowed = true, bool* probe_missed = nullptr) {
     o.outcome = OUT_MISS;
     o.status = 0;
@@ -1357,7 +1400,7 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
         BMO_NOUNROLL
         for (int r = 0; r < 3; ++r) {
             const RayS ray = pick_ray(r, g.c, g.w, g.d);
-            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, probing, probe_obj, false, nullptr);
+            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, probing, probe_obj, false, nullptr);
             if (r == 0) o.Xc = X;
             else if (r == 1) o.Xw = X;
             else o.Xd = X;

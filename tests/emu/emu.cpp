@@ -124,7 +124,9 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             if ((r.flags & 1) || (old >= 0 && !probe && !fresh_allowed)) {
                 status = BMO_NODE_RMAX;
             } else {
-                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, probe, probe_obj, fresh_allowed, &missed);
+                double ccv[BMO_CC_MAX];
+                ChildCache cc{ccv, 1, 0};
+                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, probe, probe_obj, fresh_allowed, &missed);
                 if (X.shape < 0) status = (old >= 0 && missed && !fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 else {
                     interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
@@ -372,7 +374,9 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             }
             if ((r.flags & 1) || (old >= 0 && !probe && !fresh_allowed)) status = BMO_NODE_RMAX;
             else {
-                gauss_step<true, true>(S, r.g, r.o, c, probe, probe_obj, fresh_allowed, &missed);
+                double ccv[BMO_CC_MAX];
+                ChildCache cc{ccv, 1, 0};
+                gauss_step<true, true>(S, r.g, r.o, c, cc, probe, probe_obj, fresh_allowed, &missed);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
