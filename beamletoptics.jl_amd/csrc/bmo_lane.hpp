@@ -41,7 +41,7 @@
 namespace bmo {
 
 #if defined(BMO_EMU_STATS)  // host-only instrumentation of the test emulator (tools/emu_stats.py)
-inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0;
+inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0, g_emu_normal = 0, g_emu_normal_fd = 0;
 #endif
 
 // Scene tables can be addressed through the constant address space (scalar loads, operands in SGPRs) when the build
@@ -57,6 +57,12 @@ inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0;
 #define BMO_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
 #else
 #define BMO_UNIFORM(i) (i)
+#endif
+// BMO_WAVE_ALL(p): true when p holds in every lane of the wave that executes this statement (host: the lane itself)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BMO_WAVE_ALL(p) (__all(p) != 0)
+#else
+#define BMO_WAVE_ALL(p) (p)
 #endif
 typedef const BMO_AS bmo_shape CShape;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
@@ -573,30 +579,48 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
 }
 
 // normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
-// normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88)
+// normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88).
+//
+// probe mode (decision aid, never part of a result): returns {f(p + hd*dir), f(p - hd*dir), 0} for the arg-min child's sdf f,
+// evaluated at the stencil call site, so that the caller can estimate the directional derivative dir . grad f with TWO plain
+// evaluations instead of a dual-number gradient (see intersect_shape, start classification).
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child) {
+BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child, bool probe, const d3& dir, double hd) {
     CShape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
-    v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
-    Dual y = sdf_simple<Dual, ASPH>(S, sh, x);
-    d3 n = normalize_inv(d3{y.a, y.b, y.c});
-    if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
+    if (!probe) {
+#if defined(BMO_EMU_STATS)
+        ++g_emu_normal;
+#endif
+        v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
+        Dual y = sdf_simple<Dual, ASPH>(S, sh, x);
+        d3 n = normalize_inv(d3{y.a, y.b, y.c});
+        if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
+#if defined(BMO_EMU_STATS)
+        ++g_emu_normal_fd;
+#endif
+    }
     const double e = S.grad_h;
     double g0 = 0, g1 = 0, g2 = 0;
     BMO_NOUNROLL
-    for (int q = 0; q < 6; ++q) {  // +x -x +y -y +z -z ; the untouched components get +0.0 / -0.0 like Point3(eps,0,0)
+    for (int q = probe ? 6 : 0; q < (probe ? 8 : 6); ++q) {  // +x -x +y -y +z -z ; the untouched components get +0.0 / -0.0 like Point3(eps,0,0)
         const int ax = q >> 1;
         const bool minus = q & 1;
         double ox = ax == 0 ? e : 0.0, oy = ax == 1 ? e : 0.0, oz = ax == 2 ? e : 0.0;
         v3<double> pt = minus ? v3<double>{p.x - ox, p.y - oy, p.z - oz} : v3<double>{p.x + ox, p.y + oy, p.z + oz};
+        if (q == 6) pt = v3<double>{p.x + hd * dir.x, p.y + hd * dir.y, p.z + hd * dir.z};
+        if (q == 7) pt = v3<double>{p.x - hd * dir.x, p.y - hd * dir.y, p.z - hd * dir.z};
+#if defined(BMO_EMU_STATS)
+        ++g_emu_sdf_leaf;
+#endif
         double v = sdf_simple<double, ASPH>(S, sh, pt);
-        double contrib = minus ? -v : v;
         // f(p+h) - f(p-h): the '+' value is stored first, the '-' value subtracted from it
-        if (ax == 0) g0 = minus ? g0 - v : v;
+        if (q == 6) g0 = v;
+        else if (q == 7) g1 = v;
+        else if (ax == 0) g0 = minus ? g0 - v : v;
         else if (ax == 1) g1 = minus ? g1 - v : v;
         else g2 = minus ? g2 - v : v;
-        (void)contrib;
     }
+    if (probe) return d3{g0, g1, 0.0};
     return normalize_div(d3{g0, g1, g2});
 }
 
@@ -689,63 +713,93 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
     d3 pos = pos0, dir = dir0;
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
     int i_out = 1, i_in = 1;
-    bool back = false;
+    bool back = false, classify_full = false;
+    // `pending`: this lane stands on the surface (start classification) or has converged (hit) and needs a normal.  The normal
+    // (dual-number gradient, by far the most expensive piece) is evaluated only when EVERY lane of the wave still inside this
+    // loop is pending, so the wave runs that code once per round instead of once per iteration in which some lane converges.
+    // Pure scheduling: each lane's arithmetic and its order are untouched (on the host emulator the vote is the lane itself).
+    bool pending = false;
+    int32_t bc = 0;
+    double d = 0.0;
     child_cache_reset(cc);
     for (;;) {
-        double moved = 0.0;  // how far this iteration moved the evaluation point (Lipschitz memory of the union children)
-        if (phase == INSIDE) {
-            pos = axpy3(pos, S.eps_ins, dir);
-            t_in += S.eps_ins;
-            moved = S.eps_ins;
-        } else if (phase == OUTSIDE) {
-            pos = axpy3(pos, dist, dir);
-            moved = fabs(dist);
-        }
-        int32_t bc;
-        const double d = sdf_any<ASPH>(S, s, pos, bc, cc, moved);
-        bool want_normal = false;
-        if (phase == CLASSIFY) {
-            if (d > S.eps_srf) {
-                phase = OUTSIDE;
+        if (!pending) {
+            double moved = 0.0;  // how far this iteration moved the evaluation point (Lipschitz memory of the union children)
+            if (phase == INSIDE) {
+                pos = axpy3(pos, S.eps_ins, dir);
+                t_in += S.eps_ins;
+                moved = S.eps_ins;
+            } else if (phase == OUTSIDE) {
+                pos = axpy3(pos, dist, dir);
+                moved = fabs(dist);
+            }
+            d = sdf_any<ASPH>(S, s, pos, bc, cc, moved);
+            bool give_up = false;  // the reference returns `nothing` here
+            if (phase == CLASSIFY) {
+                if (d > S.eps_srf) {
+                    phase = OUTSIDE;
+                    dist = d;
+                    t0 = d;
+                    i_out = 1;
+                    give_up = !(i_out <= S.march_iters) || (exact && t0 > t_limit);
+                } else {
+                    pending = true;
+                }
+            } else if (phase == INSIDE) {
+                if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
+                    phase = OUTSIDE;
+                    back = true;
+                    dir = neg3(dir);
+                    dist = d;
+                    t0 = d;
+                    i_out = 1;
+                    give_up = !(i_out <= S.march_iters);
+                } else {
+                    i_in += 1;
+                    give_up = !(i_in <= S.march_iters);
+                }
+            } else {
                 dist = d;
-                t0 = d;
-                i_out = 1;
-                if (!(i_out <= S.march_iters)) return h;
-                if (exact && t0 > t_limit) return h;
-                continue;
+                t0 += d;
+                i_out += 1;
+                if (d < S.eps_ray) {
+                    pending = true;
+                } else {
+                    give_up = cull_receding(s, pos, dir)                // provable miss: skip the rest of the 1000 evaluations
+                              || (exact && !back && t0 > t_limit)       // provable loser of the nearest-hit selection
+                              || !(i_out <= S.march_iters);
+                }
             }
-            want_normal = true;
-        } else if (phase == INSIDE) {
-            if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
-                phase = OUTSIDE;
-                back = true;
-                dir = neg3(dir);
-                dist = d;
-                t0 = d;
-                i_out = 1;
-                if (!(i_out <= S.march_iters)) return h;
-                continue;
-            }
-            i_in += 1;
-            if (!(i_in <= S.march_iters)) return h;
-            continue;
-        } else {
-            dist = d;
-            t0 += d;
-            i_out += 1;
-            if (d < S.eps_ray) want_normal = true;
-            else {
-                if (cull_receding(s, pos, dir)) return h;  // provable miss: skip the rest of the 1000 evaluations
-                if (exact && !back && t0 > t_limit) return h;  // provable loser of the nearest-hit selection
-                if (!(i_out <= S.march_iters)) return h;
-                continue;
-            }
+            if (give_up) return h;
         }
+        if (!BMO_WAVE_ALL(pending)) continue;
+        pending = false;
+        const bool probe = phase == CLASSIFY && exact && !classify_full && s.bs_radius > 0.0;
         // single normal evaluation site (classification on the surface, or hit)
-        (void)want_normal;
-        const d3 n = normal_any<ASPH>(S, s, pos, bc);
+        // Start classification (AbstractSDF.jl:152-165) only needs the SIGN of dot(dir, normal): entering or leaving.  For an exact
+        // (unit-gradient) sdf that sign is the sign of the directional derivative of the arg-min child's sdf f along dir.  Two plain
+        // evaluations at p +- hd*dir (hd = 1e-5 bounding radii) give the one-sided slopes g+ and g-: for a smooth f they agree to
+        // hd*f'' ~ 1e-5 and equal the derivative to that accuracy (rounding ~1e-17/hd); the reference's normal gives
+        // dot = that derivative to 1e-8 (dual numbers ~1e-15; its central-difference fallback ~1e-8).  The shortcut is taken only
+        // when |g+ - g-| <= 1e-3 (no kink of f within hd of p along the ray) and |g| > 0.05 (less than 87.1 deg from the normal);
+        // grazing rays, kinks, NaNs and inexact (aspheric) shapes take the reference's normal.  The hit normal further down is
+        // always the reference's.
+        const double hd = 1e-5 * s.bs_radius;
+        const d3 n = normal_any<ASPH>(S, s, pos, bc, probe, dir, hd);
         if (phase == CLASSIFY) {
-            if (dot3(dir, n) <= 0) {
+            bool entering;
+            if (probe) {
+                const double gp = (n.x - d) / hd, gm = (d - n.y) / hd, g = 0.5 * (gp + gm);
+                if (!(fabs(gp - gm) <= 1e-3) || !(fabs(g) > 0.05)) {
+                    classify_full = true;
+                    pending = true;  // same point, the reference's normal this time
+                    continue;
+                }
+                entering = g < 0.0;
+            } else {
+                entering = dot3(dir, n) <= 0;
+            }
+            if (entering) {
                 phase = INSIDE;
                 t_in = 0.0;
                 i_in = 1;

@@ -86,7 +86,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     int steps = 0;
     while (!cur.empty()) {
 #if defined(BMO_EMU_STATS)
-        const long a0 = g_emu_sdf_any, l0 = g_emu_sdf_leaf;
+        const long a0 = g_emu_sdf_any, l0 = g_emu_sdf_leaf, n0 = g_emu_normal, f0 = g_emu_normal_fd;
         const size_t m0 = cur.size();
 #endif
         std::vector<Rec> surv, kids;
@@ -189,8 +189,8 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
         }
         all.insert(all.end(), cur.begin(), cur.end());
 #if defined(BMO_EMU_STATS)
-        fprintf(stderr, "step %2d records %6zu  union sdf evals/record %7.2f  leaf sdf evals/record %7.2f\n", steps, m0, double(g_emu_sdf_any - a0) / m0,
-                double(g_emu_sdf_leaf - l0) / m0);
+        fprintf(stderr, "step %2d records %6zu  union sdf evals/record %7.2f  leaf sdf evals/record %7.2f  dual normals/record %5.2f  numeric fallbacks/record %5.2f\n",
+                steps, m0, double(g_emu_sdf_any - a0) / m0, double(g_emu_sdf_leaf - l0) / m0, double(g_emu_normal - n0) / m0, double(g_emu_normal_fd - f0) / m0);
 #endif
         cur = surv;
         cur.insert(cur.end(), kids.begin(), kids.end());
