@@ -200,6 +200,9 @@ __device__ inline int prefix_rank(unsigned long long mask) {
 // "dequeue"): one atomic per wave = 16 K per 1 M-ray launch put a ~0.3 ms floor under every launch.  Here the 4 waves
 // of a block publish their ballot counts in LDS, thread 0 issues ONE atomic per counter, and every wave derives its
 // own offsets.  Block layout in the next chunk: [survivors of wave 0..3][child pairs of wave 0..3].
+#ifndef BMO_BLOCK
+#define BMO_BLOCK 256  /* lanes per workgroup of the step kernels (a multiple of 64, at most 256) */
+#endif
 struct SlotAlloc {
     unsigned long long surv_base, child_base, node_base;
     unsigned long long m_surv, m_split;
@@ -210,6 +213,17 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
     SlotAlloc a;
     a.m_surv = __ballot(survive);
     a.m_split = __ballot(split);
+#if defined(BMO_EXPERIMENT_IDENTITY)  /* timing experiment only (no deaths, no splits): no barrier, no atomics, slot = own index */
+    {
+        unsigned int cc0 = calls;
+        for (int off = 32; off > 0; off >>= 1) cc0 += __shfl_down(cc0, off);
+        if (lane_id() == 0 && cc0) atomicAdd(&P.call_shards[(blockIdx.x & 63u) * 16u], (unsigned long long)cc0);
+        a.surv_base = (unsigned long long)blockIdx.x * BMO_BLOCK + (threadIdx.x & ~63u);
+        a.m_surv = ~0ull;
+        a.child_base = a.node_base = 0;
+        return a;
+    }
+#endif
     const int wave = (int)(threadIdx.x >> 6);
     unsigned int c = calls;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -220,8 +234,12 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t ts = w32[0] + w32[1] + w32[2] + w32[3], tp = w32[4] + w32[5] + w32[6] + w32[7];
-        const uint32_t tc = w32[8] + w32[9] + w32[10] + w32[11];
+        uint32_t ts = 0, tp = 0, tc = 0;
+        for (int w = 0; w < BMO_BLOCK / 64; ++w) {
+            ts += w32[w];
+            tp += w32[4 + w];
+            tc += w32[8 + w];
+        }
         unsigned long long b = 0, nb = 0;
         if (ts + tp) b = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(ts + 2 * tp));
         if (tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
@@ -231,7 +249,7 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
     }
     __syncthreads();
     uint32_t ps = 0, pp = 0, ts = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < BMO_BLOCK / 64; ++w) {
         if (w < wave) {
             ps += w32[w];
             pp += w32[4 + w];
@@ -269,7 +287,7 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
 }
 
 template <int KIND, bool LDS, bool ASPH, bool RETR>
-__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) {
+__global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
     char* scratch = lds + (LDS ? P.blob_bytes : 0u);
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
             status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
         } else {
             // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
-            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, 256, 0};
+            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
             X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hobj, hshape, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             if (X.shape < 0) {
                 status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel(StepParams P) 
 
 // ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
 template <bool LDS, bool ASPH, bool RETR>
-__global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
+__global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
     char* scratch = lds + (LDS ? P.blob_bytes : 0u);
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(256, BMO_MIN_WAVES) void step_kernel_gauss(StepPara
         if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;
         } else {
-            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, 256, 0};
+            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
             gauss_step<ASPH, RETR>(S, g, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
@@ -1045,7 +1063,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipGetLastError());
         DBG("init kernel done");
     }
-    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)BMO_CC_MAX * 256 * 8;  // + block_alloc scratch + child cache columns
+    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)BMO_CC_MAX * BMO_BLOCK * 8;  // + block_alloc scratch + child cache columns
     void (*kern)(StepParams) = nullptr;
     const bool asph = scene->hdr.has_asphere != 0;
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
@@ -1095,12 +1113,16 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             ctxp->step_ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((m + 255) / 256)), dim3(256), lds_bytes, stream, P);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((m + BMO_BLOCK - 1) / BMO_BLOCK)), dim3(BMO_BLOCK), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps + 1], stream));
         HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
+#if defined(BMO_EXPERIMENT_IDENTITY)
+        const unsigned long long produced = steps + 2 < opts->r_max ? (unsigned long long)m : 0ull;
+#else
         const unsigned long long produced = h_ctr.next_count[steps & 1];
+#endif
         DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
@@ -1296,6 +1318,18 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     std::memcpy(sc->blob.data(), &h, sizeof h);
     if (d->n_objects) std::memcpy(sc->blob.data() + h.off_objects, d->objects, sizeof(bmo_object) * (size_t)d->n_objects);
     if (d->n_shapes) std::memcpy(sc->blob.data() + h.off_shapes, d->shapes, sizeof(bmo_shape) * (size_t)d->n_shapes);
+    for (int i = 0; i < d->n_shapes; ++i) {  // unions whose children sit back to back in the shape table: no children[] look-up on the device
+        bmo_shape* sh = reinterpret_cast<bmo_shape*>(sc->blob.data() + h.off_shapes) + i;
+        sh->flags &= ~BMO_SHAPE_FLAG_CONSECUTIVE;
+        if (sh->kind != BMO_SHAPE_UNION || sh->child_count <= 0) continue;
+        bool consecutive = true;
+        for (int c = 1; c < sh->child_count; ++c)
+            if (d->children[sh->child_begin + c] != d->children[sh->child_begin] + c) consecutive = false;
+        if (consecutive) {
+            sh->flags |= BMO_SHAPE_FLAG_CONSECUTIVE;
+            sh->tri_begin = d->children[sh->child_begin];
+        }
+    }
     if (d->n_children) std::memcpy(sc->blob.data() + h.off_children, d->children, 4 * (size_t)d->n_children);
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);

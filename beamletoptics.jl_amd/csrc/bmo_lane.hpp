@@ -374,30 +374,33 @@ BMO_HD Dual asph_leaf(CShape&, CDouble*, const Dual&, const Dual&) { return Dual
 // instantiated with ASPH = false (half the code, fewer registers).
 template <class T, bool ASPH>
 BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
-    v3<T> p = to_local(s, pt);
+    // every table read of this leaf in one batch (the reads are LDS / scalar-cache round trips of ~100 cycles each: issued one by
+    // one at their points of use they, not the arithmetic, set the pace of the march)
     const int kind = s.kind;
+    const double P0 = s.p[0], P1 = s.p[1], P2 = s.p[2], P3 = s.p[3];
+    v3<T> p = to_local(s, pt);
     if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
         T r = norm3t(p.x, p.y, p.z);
-        return kind == BMO_SHAPE_SPHERE ? r - s.p[0] : r;
+        return kind == BMO_SHAPE_SPHERE ? r - P0 : r;
     }
     if (kind == BMO_SHAPE_PLANO || kind == BMO_SHAPE_CYLINDER || kind == BMO_SHAPE_RING) {
         // SphericalLensSDF.jl:60-65, PrimitiveSDF.jl:71-76, :151-166
         double ra, ha, off, sub;
         if (kind == BMO_SHAPE_PLANO) {
-            ra = s.p[1] / 2;
-            ha = s.p[0] / 2;
-            off = s.p[0] / 2;
+            ra = P1 / 2;
+            ha = P0 / 2;
+            off = P0 / 2;
             sub = 0.0;
         } else if (kind == BMO_SHAPE_CYLINDER) {
-            ra = s.p[0];
-            ha = s.p[1];
+            ra = P0;
+            ha = P1;
             off = 0.0;
             sub = 0.0;
         } else {
-            ra = s.p[1];
-            ha = s.p[2];
+            ra = P1;
+            ha = P2;
             off = 0.0;
-            sub = s.p[0];
+            sub = P0;
         }
         T r = norm2(p.x, p.z);
         if (kind == BMO_SHAPE_RING) r = r - sub;
@@ -405,15 +408,15 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
         return slab2(jabs(r) - ra, jabs(h) - ha);
     }
     if (kind == BMO_SHAPE_CONVEX || kind == BMO_SHAPE_CUTSPHERE) {  // SphericalLensSDF.jl:219-232, PrimitiveSDF.jl:112-124
-        double radius = s.p[0], w, height;
+        double radius = P0, w, height;
         T q1 = norm2(p.x, p.z), q2;
         if (kind == BMO_SHAPE_CONVEX) {
-            w = s.p[1] / 2;
-            height = s.p[3];
+            w = P1 / 2;
+            height = P3;
             q2 = -p.y + radius;
         } else {
-            height = s.p[1];
-            w = s.p[2];
+            height = P1;
+            w = P2;
             q2 = p.y;
         }
         double a = val(q1), b = val(q2);
@@ -423,7 +426,7 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
         return norm2(q1 - w, q2 - height);
     }
     if (kind == BMO_SHAPE_CONCAVE) {  // SphericalLensSDF.jl:159-170
-        double radius = s.p[0], dia = s.p[1], sag = s.p[2];
+        double radius = P0, dia = P1, sag = P2;
         T x0 = p.x + 0.0, z0 = p.z + 0.0;
         T y1 = p.y + sag / 2;
         T r = norm2(x0, z0);
@@ -433,7 +436,7 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
         return jmax(sdf1, -sdf2);
     }
     if (kind == BMO_SHAPE_BOX || kind == BMO_SHAPE_PRISM) {  // PrimitiveSDF.jl:41-46, :204-210
-        T qx = jabs(p.x) - s.p[0], qy = jabs(p.y) - s.p[1], qz = jabs(p.z) - s.p[2];
+        T qx = jabs(p.x) - P0, qy = jabs(p.y) - P1, qz = jabs(p.z) - P2;
         T box = norm3t(jmax(qx, 0.0), jmax(qy, 0.0), jmax(qz, 0.0)) + jmin(jmax(qx, jmax(qy, qz)), 0.0);
         if (kind == BMO_SHAPE_BOX) return box;
         T pln = (p.x + p.y) / 1.4142135623730951;  // sqrt(2)
@@ -447,13 +450,13 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
     }
     if constexpr (ASPH) {
         if (kind == BMO_SHAPE_ACYL_CONVEX || kind == BMO_SHAPE_ACYL_CONCAVE) {  // AcylindricalSDF.jl:55-74, :122-141
-            const double height = s.p[2];
-            T d2 = asph_distance<T>(kind == BMO_SHAPE_ACYL_CONVEX, p.z, p.y, 1 / s.p[0], s.p[3], s.p[1], coefs + s.child_begin, s.child_count, s.p[4]);
+            const double height = P2;
+            T d2 = asph_distance<T>(kind == BMO_SHAPE_ACYL_CONVEX, p.z, p.y, 1 / P0, P3, P1, coefs + s.child_begin, s.child_count, s.p[4]);
             T w2 = jabs(p.x) - height / 2;
             return jmin(jmax(d2, w2), 0.0) + norm2(jmax(d2, 0.0), jmax(w2, 0.0));
         }
         if (kind == BMO_SHAPE_CYL_CONVEX) {  // CylindricalSDF.jl:62-85: op_extrude_x of sdf_cut_disk
-            const double r = s.p[0], dia = s.p[1], height = s.p[2];
+            const double r = P0, dia = P1, height = P2;
             const double h = sqrt(r * r - (dia / 2) * (dia / 2));
             const double w = sqrt(r * r - h * h);
             T q1 = jabs(p.y), q2 = p.z;
@@ -464,7 +467,7 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
             return jmin(jmax(d2, w2), 0.0) + norm2(jmax(d2, 0.0), jmax(w2, 0.0));
         }
         if (kind == BMO_SHAPE_CYL_CONCAVE) {  // CylindricalSDF.jl:123-139
-            const double radius = s.p[0], dia = s.p[1], height = s.p[2];
+            const double radius = P0, dia = P1, height = P2;
             const double ar = fabs(radius);
             const double sg = ar - sqrt(ar * ar - 0.25 * (dia * dia));
             T x0 = p.x + 0.0, z0 = p.z + 0.0;
@@ -536,21 +539,28 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
     bool have = false;
     const int first = (uni && cc.prev_best < nch) ? cc.prev_best : 0;
     const double slack = moved * (1.0 + 1e-9) + 1e-12;  // |dir| is 1 only to rounding
+    // children stored back to back in the shape table (the usual case; flagged by the engine when it copies the scene): child c is
+    // shape first_id + c, no look-up in children[]
+    const bool consecutive = uni && (s.flags & BMO_SHAPE_FLAG_CONSECUTIVE);
+    const int32_t cb = s.child_begin, first_id = s.tri_begin;
     BMO_NOUNROLL
     for (int q = 0; q < nch; ++q) {
         const int c = q == 0 ? first : (q <= first ? q - 1 : q);
-        CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[S.children[s.child_begin + BMO_UNIFORM(c)]] : &s);
+        CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[consecutive ? first_id + BMO_UNIFORM(c) : S.children[cb + BMO_UNIFORM(c)]] : &s);
+        const int32_t ch_flags = ch.flags;  // one batch with the bounding sphere
+        const double ch_r = ch.bs_radius, ch_cx = ch.bs_center[0], ch_cy = ch.bs_center[1], ch_cz = ch.bs_center[2];
+        const double cached = (uni && c < BMO_CC_MAX) ? cc.v[c * cc.stride] : -kinf();  // same batch
         bool skip = false;
         double lb = -kinf();
-        if (have && !(ch.flags & BMO_SHAPE_FLAG_INEXACT)) {
+        if (have && !(ch_flags & BMO_SHAPE_FLAG_INEXACT)) {
             const double bound = best > 0.0 ? best : 0.0;
-            if (ch.bs_radius >= 0.0) {
-                const double ox = p.x - ch.bs_center[0], oy = p.y - ch.bs_center[1], oz = p.z - ch.bs_center[2];
-                const double lim = ch.bs_radius + bound;
+            if (ch_r >= 0.0) {
+                const double ox = p.x - ch_cx, oy = p.y - ch_cy, oz = p.z - ch_cz;
+                const double lim = ch_r + bound;
                 skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
             }
             if (!skip && c < BMO_CC_MAX) {
-                lb = cc.v[c * cc.stride] - slack;
+                lb = cached - slack;
                 skip = lb > bound + 1e-12;
             }
         }

@@ -161,6 +161,14 @@ def main():
         alg_bytes_step = traced * BYTES_PER_BOUNCE + hits * BYTES_PER_HIT  # this rank, one step
         avg_launch_ms = kernel_ms / max(launches, 1)
         achieved = alg_bytes_step * args.steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this timed
+        # process): bytes per launch, measured with the same command at the default workload; null for any other workload.
+        traffic, traffic_src = None, None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_c2_1M.json")
+        if os.path.exists(tp) and n_local == (1 << 20) and args.r_max == 100:
+            tj = json.load(open(tp))
+            traffic = (tj["fetch_bytes"] + tj["write_bytes"]) / tj["launches"]
+            traffic_src = tj["source"]
         out = {
             "metric": "ray-surface intersections/s",
             "value": value,
@@ -183,7 +191,8 @@ def main():
                 "intersect3d_calls_per_step": int(calls_all), "parallelism": f"ray-shard x{world}" + (" + RCCL all-gather of detector hits" if world > 1 else ""),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "kernel": "step_kernel<RAY>", "launches_per_step": launches // max(args.steps, 1), "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": alg_bytes_step / max(launches // max(args.steps, 1), 1),
                 "note": "path is FP64-VALU/latency bound (SURVEY.md §8d): algorithmic HBM bytes are 184 B/bounce + 16 B/hit; "

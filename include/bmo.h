@@ -90,6 +90,9 @@ enum bmo_shape_kind {
 /* The SDF is a first-order distance ESTIMATE (aspheres: |z - z(r)| / |grad|), not 1-Lipschitz: only the bounding-sphere
  * culls apply to it, not the running-t prune nor the union child skip (DESIGN.md "miss cull").  Unions inherit it. */
 #define BMO_SHAPE_FLAG_INEXACT 1
+/* Library-internal (set by bmo_scene_create on its own copy of the tables, ignored on input): the children of this UNION are
+ * consecutive shape ids starting at tri_begin (unused by unions otherwise), so the walk over children needs no children[] read. */
+#define BMO_SHAPE_FLAG_CONSECUTIVE 2
 
 typedef struct bmo_shape {
     int32_t kind;
