@@ -213,17 +213,6 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
     SlotAlloc a;
     a.m_surv = __ballot(survive);
     a.m_split = __ballot(split);
-#if defined(BMO_EXPERIMENT_IDENTITY)  /* timing experiment only (no deaths, no splits): no barrier, no atomics, slot = own index */
-    {
-        unsigned int cc0 = calls;
-        for (int off = 32; off > 0; off >>= 1) cc0 += __shfl_down(cc0, off);
-        if (lane_id() == 0 && cc0) atomicAdd(&P.call_shards[(blockIdx.x & 63u) * 16u], (unsigned long long)cc0);
-        a.surv_base = (unsigned long long)blockIdx.x * BMO_BLOCK + (threadIdx.x & ~63u);
-        a.m_surv = ~0ull;
-        a.child_base = a.node_base = 0;
-        return a;
-    }
-#endif
     const int wave = (int)(threadIdx.x >> 6);
     unsigned int c = calls;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -1118,11 +1107,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-#if defined(BMO_EXPERIMENT_IDENTITY)
-        const unsigned long long produced = steps + 2 < opts->r_max ? (unsigned long long)m : 0ull;
-#else
         const unsigned long long produced = h_ctr.next_count[steps & 1];
-#endif
         DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
