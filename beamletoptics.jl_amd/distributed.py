@@ -17,26 +17,49 @@ def shard_bounds(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
-def all_gather_hits(local_hits, group=None):
+class PendingGather:
+    """An all-gather of hit buffers in flight (async_op): wait() -> (hits [total, width] in reference order, counts [world])."""
+
+    def __init__(self, work, outs, counts):
+        self.work, self.outs, self.counts = work, outs, counts
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        world = len(self.outs)
+        hits = torch.cat([self.outs[r][: int(self.counts[r])] for r in range(world)], dim=0)
+        return hits, self.counts
+
+
+def all_gather_hits(local_hits, group=None, async_op=False):
     """All-gather variable-length hit buffers.
 
-    local_hits: tensor [count, 9] float64 on this rank's device (CUDA for nccl, CPU for gloo).
-    Returns (hits [total, 9] in reference order, counts [world]).  Counts are exchanged first, then buffers padded to
-    the maximum count (one collective each), then trimmed and concatenated in rank order.
+    local_hits: tensor [count, width] float64 on this rank's device (CUDA for nccl, CPU for gloo); width is 9 for the full hit
+    record (include/bmo.h det_data) or fewer leading columns (a Spotdetector only uses x, y).
+    Returns (hits [total, width] in reference order, counts [world]).  Counts are exchanged first (one tiny collective), then
+    buffers padded to the maximum count, trimmed and concatenated in rank order.  With async_op the payload collective is
+    left in flight (PendingGather) so that it overlaps the next trace; call .wait() before using the result.
     """
     world = dist.get_world_size(group)
     dev = local_hits.device
+    width = local_hits.shape[1]
     cnt = torch.tensor([local_hits.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt, group=group)
     counts = torch.cat(counts).cpu()
     mx = max(int(counts.max()), 1)
-    buf = torch.zeros((mx, HIT_WIDTH), dtype=torch.float64, device=dev)
+    buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
     buf[: local_hits.shape[0]] = local_hits
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    hits = torch.cat([outs[r][: int(counts[r])] for r in range(world)], dim=0)
-    return hits, counts
+    if dist.get_backend(group) == "nccl":  # one contiguous receive buffer: no per-rank copy kernels after the ring all-gather
+        flat = torch.empty((world * mx, width), dtype=torch.float64, device=dev)
+        work = dist.all_gather_into_tensor(flat, buf, group=group, async_op=True)
+        outs = [flat[r * mx:(r + 1) * mx] for r in range(world)]
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        work = dist.all_gather(outs, buf, group=group, async_op=True)
+    pending = PendingGather(work, outs, counts)
+    return pending if async_op else pending.wait()
 
 
 def all_reduce_field(field, group=None):

@@ -98,25 +98,34 @@ def main():
     dev_batch = eng.upload(bundle)
     n_det = len(scene.detectors)
 
+    det_width = [2 if d.kind == bmo.components.O_SPOT else 9 for d in scene.detectors]  # a Spotdetector stores (x, y) only
+    in_flight = []  # exchange step of the previous trace, still travelling
+
+    def finish_exchange():
+        out = [g.wait() for g in in_flight]  # (hits in reference order, counts) per detector
+        in_flight.clear()
+        return out
+
     def one_step():
         res = eng.trace_device(dev_batch, args.r_max)
         kms, tms, nl = eng.result_timing(res)
         counts = [eng.result_device_hits(res, s)[1] for s in range(n_det)]
-        gathered = None
         if world > 1:
-            # all-gather of detector hits over xGMI: counts first, then padded buffers (hits are 9 x f64 records)
-            gathered = []
+            # Exchange step: all-gather of the detector hit lists over xGMI — counts first, then the payload
+            # (the columns the detector keeps), left in flight so that it overlaps the NEXT trace (separate RCCL stream);
+            # the previous step's exchange is completed first, and the last one inside the timed region (sync()).
+            finish_exchange()
             for s in range(n_det):
                 local = torch.empty((counts[s], 9), dtype=torch.float64, device="cuda")
                 eng.result_copy_hits(res, s, local.data_ptr(), counts[s])
-                gathered.append(bd.all_gather_hits(local if backend == "nccl" else local.cpu()))  # hits in reference order
-            torch.cuda.synchronize()
-        view = None
+                payload = local[:, : det_width[s]].contiguous()
+                in_flight.append(bd.all_gather_hits(payload if backend == "nccl" else payload.cpu(), async_op=True))
         stats = dict(kernel_ms=kms, total_ms=tms, launches=nl, hits=counts)
         return res, stats
 
     def sync():
         if world > 1:
+            finish_exchange()
             dist.barrier()
             torch.cuda.synchronize()
 
