@@ -485,6 +485,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
         g.E0 = {P.nodes.aux[(int64_t)node * 4 + 2], P.nodes.aux[(int64_t)node * 4 + 3]};
         int status = 0;
         o.Xc = o.Xw = o.Xd = no_hit();
+        o.det = P.nodes.hit + (int64_t)node * 27;  // a detector hit ends the beamlet: its records go straight to the node's slot
         if (RETR) {
             rt = retrace_lane(P, node, k);
             if (rt.old >= 0 && !rt.probe) g.hint_obj = g.hint_shape = -1;
@@ -521,10 +522,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
         if (!survive) {
             P.nodes.nseg[node] = k + 1;
             P.nodes.status[node] = status;
-            if (o.det_slot >= 0 && !(flags & F_DEAD)) {
-                P.nodes.hit_det[node] = o.det_slot;
-                for (int c = 0; c < 27; ++c) P.nodes.hit[(int64_t)node * 27 + c] = o.det[c];
-            }
+            if (o.det_slot >= 0 && !(flags & F_DEAD)) P.nodes.hit_det[node] = o.det_slot;
         }
     }
     const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
@@ -902,6 +900,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         Counters* pinned = nullptr;
         std::vector<hipEvent_t> step_ev;
+        std::mutex busy;  // one trace at a time per device: the stream, events and pinned counters are shared
     };
     static std::mutex ctx_mu;
     static std::vector<std::pair<int, std::unique_ptr<DevCtx>>> ctxs;
@@ -920,6 +919,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
     }
     DevCtx& ctx = *ctxp;
+    std::lock_guard<std::mutex> one_trace_per_device(ctx.busy);
     hipStream_t stream = ctx.stream;
     hipEvent_t ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
     HIP_TRY(hipEventRecord(ev_t0, stream));

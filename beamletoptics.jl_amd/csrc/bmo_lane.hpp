@@ -1343,7 +1343,7 @@ struct GaussOut {
     RayS nc, nw, nd;  // next segment, or transmitted child
     RayS rc, rw, rd;  // reflected child
     int det_slot, n_det;
-    double det[27];
+    double* det;  // destination of the detector record(s) of this beamlet, 3 x 9 doubles (the node's hit slot): written in place
     double child_w0, child_l0;
     cx Et, Er;
     double oplC, oplW, oplD, lenA, lenB;  // accumulators for the next segment

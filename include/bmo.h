@@ -19,6 +19,11 @@
  * are exceptions in the reference (non-unit vectors OpticUtils.jl:33-35, ...)
  * are reported per beam node in node_status so the wrapper can re-raise them.
  *
+ * Threading: a bmo_scene is immutable after creation and may be shared between threads; trace / retrace calls may be issued
+ * from several host threads (the reference's trace loop is single-threaded, System.jl:239, :403) — calls for the same device
+ * are serialised inside the library (one trace stream per device), calls for different devices run concurrently.  A
+ * bmo_trace_result may be read (view, hits, retrace source, read-outs) from one thread at a time.
+ *
  * The library is libbmo_hip.so (HIP, gfx950).  There is no CPU fallback inside
  * it: every trace call needs a GPU and fails with BMO_ERR_NO_DEVICE otherwise.
  * The independent CPU restatement of the reference algorithm lives in oracle/

@@ -359,6 +359,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             r.o.Xc = r.o.Xw = r.o.Xd = no_hit();
             r.o.outcome = OUT_MISS;
             r.o.det_slot = -1;
+            r.o.det = nodes[r.node].hit;
             const int old = nodes[r.node].old;
             bool probe = false, fresh_allowed = true, missed = false;
             int probe_obj = -1, old_n = 0;
@@ -391,10 +392,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                 if (old_kids && r.o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
-                if (r.o.det_slot >= 0 && !(r.flags & 1)) {
-                    nodes[r.node].hit_det = r.o.det_slot;
-                    std::memcpy(nodes[r.node].hit, r.o.det, sizeof r.o.det);
-                }
+                if (r.o.det_slot >= 0 && !(r.flags & 1)) nodes[r.node].hit_det = r.o.det_slot;
             }
             auto next = [&](const RayS& c1, const RayS& w1, const RayS& d1, int node, int k, int ho, int hs, int fl, double lenA, double lenB,
                             double oplC, double oplW, double oplD, const GNode& nd) {
