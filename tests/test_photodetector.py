@@ -261,3 +261,112 @@ def test_gpu_kat_michelson_unequal_arm_field(oracle):
 @pytest.mark.gpu
 def test_gpu_kat_power_conservation():
     power_conservation(bmo.solve_system, n_phi=7)
+
+
+# ------------------------------------------------------------------------------------------------ "Bug fixes" KATs (runtests.jl:2813-2925)
+def test_kat_issue14_tilted_beam_power(oracle):  # runtests.jl:2814-2829
+    pd = bmo.Photodetector(10e-3, 1000)
+    bmo.zrotate3d(pd, math.radians(90))
+    bmo.translate3d(pd, [0.46, 0, 0])
+    y_0 = 0.2
+    beam = bmo.GaussianBeamlet([0, y_0, 0], [0.46, -y_0, 0], 532e-9, 2.5e-3, P0=10e-3)
+    pd.empty()
+    oracle.solve_system(bmo.System([pd]), beam)
+    assert abs(pd.optical_power() - 10e-3) <= 1e-5
+
+
+def _issue22_setup(n_substrate=1.5):
+    splitter = bmo.CubeBeamsplitter(10 * mm, lambda lam: 1)
+    substrate_length = 10 * mm
+    substrate = bmo.Lens(bmo.shapes.CylinderSDF(5 * mm, substrate_length / 2), n_substrate)  # TestSubstrate <: AbstractRefractiveOptic
+    detector = bmo.Photodetector(10 * mm, 250)
+    bmo.translate3d(substrate, [0, -25 * mm, 0])
+    bmo.translate3d(detector, [0, 40 * mm, 0])
+    return bmo.System([substrate, splitter, detector]), substrate, detector, substrate_length
+
+
+def _set_index(substrate, n):
+    substrate.n = bmo.components._as_index(n)
+
+
+def _shift_phase(gb, phase):  # electric_field!(gb, electric_field(gb) * exp(im*phase))
+    gb.E0 = gb.E0 * np.exp(1j * phase)
+
+
+def _ref_signal(phi, A):
+    return (math.cos(phi) + 1) / 2 * A
+
+
+def visibility(I):  # OpticUtils.jl interferometric visibility
+    return (I.max() - I.min()) / (I.max() + I.min())
+
+
+@pytest.mark.parametrize("index", [1, 10, 100, 1000])
+def test_kat_issue22_visibility_for_any_substrate_index(oracle, index):  # runtests.jl:2866-2883
+    system, substrate, detector, L = _issue22_setup()
+    start_offset = 50 * mm
+    _set_index(substrate, index)
+    phis = bmo.linalg.linrange(0, 2 * math.pi, 30)
+    power = np.zeros(len(phis))
+    for i, p in enumerate(phis):
+        gb_prb = bmo.GaussianBeamlet([0, -start_offset, 0], [0, 1, 0], 1e-6, 0.5 * mm)
+        gb_ref = bmo.GaussianBeamlet([start_offset, 0, 0], [-1, 0, 0], 1e-6, 0.5 * mm)
+        detector.empty()
+        _shift_phase(gb_ref, p)
+        oracle.solve_system(system, gb_prb)
+        oracle.solve_system(system, gb_ref)
+        power[i] = detector.optical_power()
+    assert abs(visibility(power) - 1) <= 1e-2
+
+
+def issue23_index_phase_shift(solve, n_steps):
+    """runtests.jl:2885-2908: the substrate index rises until one more wavelength of OPL is in the probe arm; both beams are
+    re-solved (retraced) every step."""
+    system, substrate, detector, L = _issue22_setup()
+    lam, start_offset = 1e-6, 50 * mm
+    gb_prb = bmo.GaussianBeamlet([0, -start_offset, 0], [0, 1, 0], lam, 0.5 * mm)
+    gb_ref = bmo.GaussianBeamlet([start_offset, 0, 0], [-1, 0, 0], lam, 0.5 * mm)
+    n_lambdas = L / lam
+    for nf in bmo.linalg.linrange(0, 1, n_steps):
+        _set_index(substrate, 1 + 1 / n_lambdas * nf)
+        detector.empty()
+        solve(system, gb_prb)
+        solve(system, gb_ref)
+        assert abs(detector.optical_power() - _ref_signal(2 * math.pi * nf, 2e-3)) <= 1e-8
+    delta = (gb_prb.optical_path_length() - gb_ref.optical_path_length()) / lam
+    assert math.isclose(delta, 1, rel_tol=1.5e-8)
+    return gb_prb, gb_ref
+
+
+def test_kat_issue23_index_based_phase_shift(oracle):
+    issue23_index_phase_shift(oracle.solve_system, 50)
+
+
+def issue23_field_mutation(solve, n_steps):
+    """runtests.jl:2910-2923: the probe beamlet's E0 is rotated between solves; the retrace must carry the new E0 into the stored
+    children (_modify_beam_head!, Gaussian.jl:154-161).  The reference's testsets share the mutable substrate: the preceding
+    testset leaves its index at 1 + lambda/L (one extra wavelength of OPL), which is what makes ref_signal(phi) exact to 1e-8
+    here (with the constructor's n = 1.5 the plate adds a Gouy/curvature phase of 2.1e-3 rad between the arms)."""
+    system, substrate, detector, L = _issue22_setup()
+    _set_index(substrate, 1 + 1 / (L / 1e-6))
+    start_offset = 50 * mm
+    gb_prb = bmo.GaussianBeamlet([0, -start_offset, 0], [0, 1, 0], 1e-6, 0.5 * mm)
+    gb_ref = bmo.GaussianBeamlet([start_offset, 0, 0], [-1, 0, 0], 1e-6, 0.5 * mm)
+    phis = bmo.linalg.linrange(0, 2 * math.pi, n_steps)
+    for phi in phis:
+        detector.empty()
+        solve(system, gb_prb)
+        solve(system, gb_ref)
+        assert abs(detector.optical_power() - _ref_signal(phi, 2e-3)) <= 1e-8
+        _shift_phase(gb_prb, phis[1] - phis[0])
+    return gb_prb, gb_ref
+
+
+def test_kat_issue23_field_mutation_during_retracing(oracle):
+    issue23_field_mutation(oracle.solve_system, 50)
+
+
+@pytest.mark.gpu
+def test_gpu_kat_issue23_on_the_engine():
+    for b in issue23_index_phase_shift(bmo.solve_system, 12) + issue23_field_mutation(bmo.solve_system, 12):
+        bmo.release(b)
