@@ -118,6 +118,19 @@ class _MultiShape(AbstractObject):
             v = (R @ v) - v
             p._translate3d(v)
 
+    def _reset_translation3d(self):  # AbstractShapeTrait.jl:144-150 (sub-part relative translations are kept)
+        self._translate3d(-self.position())
+        self._set_position(np.zeros(3))
+
+    def _reset_rotation3d(self):  # AbstractShapeTrait.jl:160-173: undo the net rotation about its axis (sub-part rotations are kept)
+        R = self.orientation()
+        theta = math.acos(min(1.0, max(-1.0, (np.trace(R) - 1) / 2)))
+        if theta == 0:
+            return
+        axis = 1 / (2 * math.sin(theta)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        self._rotate3d(axis, -theta)
+        self._set_orientation(np.eye(3))
+
 
 class ObjectGroup(_MultiShape):
     """ObjectGroups.jl:21-47."""

@@ -146,6 +146,9 @@ BMO_HD Dual operator/(const Dual& x, double r) { return {x.v / r, x.a / r, x.b /
 BMO_HD Dual jsqrt(const Dual& x) {
     double s = sqrt(x.v);
     double d = 1.0 / (2.0 * s);
+    // sqrt(0) with all-zero partials keeps them zero (ForwardDiff's NaN-safe partial scaling; pinned by the reference's narrow
+    // point-source KAT, test/runtests.jl:2755-2761 — see oracle/jl_math.hpp)
+    if (!(fabs(d) < kinf()) && x.a == 0 && x.b == 0 && x.c == 0) return {s, x.a, x.b, x.c};
     return {s, x.a * d, x.b * d, x.c * d};
 }
 BMO_HD Dual jabs(const Dual& x) { return sgn(x.v) ? -x : x; }

@@ -284,20 +284,13 @@ def test_doublet(oracle, lam, bfl, df):  # :1273-1321
         t = np.dot(f0 - ray.pos, d) / np.dot(d, ray.dir)  # intersect3d(plane) AbstractRay.jl:162-171
         p0 = ray.pos + t * ray.dir
         assert np.linalg.norm(p0 - f0) <= 1e-6
-    # Centre-ray normals (runtests.jl:1309-1314: |n . dir| ≈ 1).  On the ROTATED doublet the exact-axis ray ends on the
-    # degenerate apex of the cemented ConcaveSphericalSurfaceSDF where sdf ~ |y| has a kink: the dual gradient is NaN
-    # (sqrt'(0)) and the central-difference fallback (AbstractSDF.jl:81-88) cancels to rounding noise, so the reference's
-    # own result there depends on last-bit noise of its kinematics and cannot be pinned (the same holds within
-    # rho < sqrt(2 R h) ~ 45 um of the axis, where the h = 1e-8 stencil straddles the kink).  We pin the assertion
-    # 100 um off axis on the rotated lens, and exactly on axis on the un-rotated lens.
-    beam = bmo.Beam(pos + 1e-4 * nv, -d, lam)
+    # Centre-ray normals, as the reference tests them (runtests.jl:1309-1314): the exact-axis ray on the ROTATED doublet, every
+    # normal parallel to the ray.  The ray ends on the apex of the cemented ConcaveSphericalSurfaceSDF, where the cylinder part of
+    # that sdf takes norm() of a zero vector: with sqrt(0) keeping zero partials (oracle/jl_math.hpp jsqrt) the dual-number normal
+    # is valid and exactly axial; with 0*Inf = NaN the central-difference fallback cancels to rounding noise there and this
+    # assertion cannot hold on the rotated lens — one of the three reference KATs that pin that rule.
+    beam = bmo.Beam(pos + 0 * nv, -d, lam)
     oracle.solve_system(system, beam)
-    assert len(beam.rays) == 4
-    for r in beam.rays[:-1]:
-        assert abs(abs(np.dot(r.intersection.n, r.dir)) - 1) < 1e-5
-    dl0 = bmo.SphericalDoubletLens(87.9e-3, -105.6e-3, math.inf, 6e-3, 3e-3, bmo.inch, NLAK22, NSF10)
-    beam = bmo.Beam([0, -0.05, 0], [0, 1.0, 0], lam)
-    oracle.solve_system(bmo.System([dl0]), beam)
     assert len(beam.rays) == 4
     for r in beam.rays[:-1]:
         assert approx(abs(np.dot(r.intersection.n, r.dir)), 1)
