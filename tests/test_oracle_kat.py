@@ -319,3 +319,42 @@ def test_lens_from_surfaces(oracle):  # :1338-1375
     lens = bmo.Lens(bmo.SphericalSurface(math.inf, d), bmo.SphericalSurface(25.7e-3, d), 3.5e-3, lambda n: 1.517)
     assert approx(lens.thickness, 3.5e-3)
     assert abs(lens.shape.sdfs[1].sag + bmo.thickness(lens.shape.sdfs[0]) - 0.006858) <= 1e-4
+
+
+mm = 1e-3
+
+
+def test_lens_from_surfaces_catalogue_shapes():  # :1393-1520 (host scene builders)
+    d = 25.4e-3
+    n = lambda lam: 1.517  # noqa: E731
+
+    def lens_of(r1, r2, l, dia=d):
+        lens = bmo.Lens(bmo.SphericalSurface(r1, dia), bmo.SphericalSurface(r2, dia), l, n)
+        assert approx(lens.thickness, l)
+        return lens.shape
+
+    s = lens_of(-39.6e-3, 39.6e-3, 3.0e-3)  # Thorlabs LD2297, bi-concave (:1393-1410)
+    assert abs(s.sdfs[1].sag + s.sdfs[2].sag + bmo.thickness(s.sdfs[0]) - 0.0072) <= 1e-4
+    s = lens_of(134.6e-3, -24.0e-3, 6.5e-3)  # LBF254-040, best form (:1412-1431)
+    assert abs(bmo.thickness(s.sdfs[0]) - 2.286e-3) <= 1e-4
+    s = lens_of(-82.2e-3, -32.1e-3, 3.6e-3)  # LE1234, positive meniscus (:1433-1451)
+    assert abs(bmo.thickness(s.sdfs[0]) + s.sdfs[1].sag - 2e-3) <= 1e-4
+    s = lens_of(-33.7e-3, -100.0e-3, 3.0e-3)  # LF1822, negative meniscus (:1453-1471)
+    assert abs(bmo.thickness(s.sdfs[0]) + s.sdfs[1].sag - 4.7e-3) <= 1e-4
+    lens_of(103.4371e-3, 61.14925e-3, 1.5e-3, 55e-3)  # generic "true" meniscus (:1473-1488)
+
+    # ring generation for mechanical diameters (:1490-1519, the miniscope elements of BASELINE config C2)
+    NBK7 = bmo.DiscreteRefractiveIndex([532e-9, 1064e-9], [1.5195, 1.5066])
+    s1 = bmo.Lens(bmo.SphericalSurface(38.184 * mm, 2 * 1.840 * mm, 2 * 2.380 * mm), bmo.SphericalSurface(3.467 * mm, 2 * 2.060 * mm, 2 * 2.380 * mm),
+                  0.5 * mm, NBK7)
+    assert abs(2 * s1.shape.sdfs[4].hthickness - 0.001134) <= 1e-6
+    s2 = bmo.Lens(bmo.SphericalSurface(3.467 * mm, 2 * 2.060 * mm, 2 * 2.380 * mm), bmo.SphericalSurface(-5.020 * mm, 2 * 2.380 * mm, 2 * 2.380 * mm),
+                  2.5 * mm, NBK7)
+    assert abs(2 * s2.shape.sdfs[3].hthickness - 0.001221590) <= 1e-8
+    a = bmo.SphericalSurface(7.744 * mm, 2 * 2.812 * mm, 2 * 3 * mm)
+    b = bmo.SphericalSurface(-3.642 * mm, 2 * 3 * mm)
+    c = bmo.SphericalSurface(-14.413 * mm, 2 * 2.812 * mm, 2 * 3 * mm)
+    dl21 = bmo.Lens(a, b, 3.4 * mm, NBK7)
+    dl22 = bmo.Lens(b, c, 1.0 * mm, NBK7)
+    assert abs(2 * dl21.shape.sdfs[3].hthickness - 0.001294398) <= 1e-6
+    assert abs(2 * dl22.shape.sdfs[3].hthickness - 0.000723025) <= 1e-6
