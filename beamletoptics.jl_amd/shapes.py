@@ -78,6 +78,15 @@ class Mesh(AbstractShape):
     def _reset_translation3d(self):  # Mesh.jl:139-142
         self._translate3d(-self.pos)
 
+    def _reset_rotation3d(self):  # Mesh.jl:149-163: rotate the vertices back about the net rotation axis, then dir = I
+        R = self.dir
+        theta = math.acos(min(1.0, max(-1.0, (np.trace(R) - 1) / 2)))
+        if theta == 0:
+            return
+        axis = 1 / (2 * math.sin(theta)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        self._rotate3d(axis, -theta)
+        self.dir = np.eye(3)
+
     def scale3d(self, s):  # Mesh.jl:127-132
         self.vertices = (self.vertices - self.pos[None, :]) * s + self.pos[None, :]
         self.scale = float(s)
