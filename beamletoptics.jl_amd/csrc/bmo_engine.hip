@@ -129,7 +129,7 @@ struct Counters {  // device-resident, one per trace
     // (the host has read it before launching step s), so no host->device reset sits between two launches.
     unsigned long long next_count[2];
     unsigned long long node_count;
-    unsigned long long calls;
+    unsigned long long max_depth;  // deepest beam-tree level created so far (sizes the sort keys of the final ordering)
     unsigned long long overflow;
 };
 
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         if (cn + 1 < P.nodes.cap) {
             const unsigned long long pkey = P.nodes.key[node];
             const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+            atomicMax(&P.ctr->max_depth, depth + 1ull);
             for (int w = 0; w < 2; ++w) {
                 const int64_t c = cn + w;
                 P.nodes.root[c] = (int32_t)root;
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
         if (cn + 1 < P.nodes.cap) {
             const unsigned long long pkey = P.nodes.key[node];
             const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+            atomicMax(&P.ctr->max_depth, depth + 1ull);
             for (int w = 0; w < 2; ++w) {
                 const int64_t c = cn + w;
                 P.nodes.root[c] = (int32_t)root;
@@ -660,6 +662,18 @@ __global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const
     const int32_t p = parent[c];
     if (p >= 0 && !(key[c] & 1ull)) first_child[p] = (int32_t)c;  // transmitted child (path bit 0); the reflected one is c + 1
 }
+// (root, depth, path) keys packed into as few bits as this solve needs: the radix sort of the final ordering runs 3-4 passes over
+// 32-bit keys instead of 8 over 64-bit ones
+__global__ void pack_keys_kernel(const unsigned long long* __restrict__ key, int64_t n, int bits_depth, int bits_path, uint32_t* __restrict__ k32,
+                                 unsigned long long* __restrict__ k64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = key[i];
+    const unsigned long long root = k >> 32, depth = (k >> 26) & 63ull, path = k & ((1ull << 26) - 1ull);
+    const unsigned long long packed = (root << (bits_depth + bits_path)) | (depth << bits_path) | path;
+    if (k32) k32[i] = (uint32_t)packed;
+    else k64[i] = packed;
+}
 __global__ void iota_kernel(int32_t* a, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) a[j] = (int32_t)j;
@@ -671,18 +685,26 @@ __global__ void hit_flags_kernel(const int32_t* order, const int32_t* hit_det, i
     const int32_t d = hit_det[order[i]];
     for (int32_t q = 0; q < n_det; ++q) flags[(int64_t)q * n + i] = (q == d) ? nsub : 0;
 }
+// offsets of every detector's segment in the compacted hit list + the total, in one small array (one read-back instead of nd + 2)
+__global__ void hit_offsets_kernel(const int32_t* __restrict__ offs, const int32_t* __restrict__ flags, int64_t n, int32_t n_det, int32_t* __restrict__ out) {
+    const int d = (int)threadIdx.x;
+    if (d < n_det) out[d] = offs[(int64_t)d * n];
+    if (d == n_det) out[d] = offs[(int64_t)n_det * n - 1] + flags[(int64_t)n_det * n - 1];
+}
+// one thread per (node, double of its hit record): the 72-byte records are read and written as contiguous runs
 __global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, const double* hit, int64_t n, int32_t nsub,
                                   const int32_t* offs, double* out, int32_t* out_node) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = 9 * nsub;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / width;
     if (i >= n) return;
+    const int k = (int)(t - i * width);
     const int32_t nd = order[i];
     const int32_t d = hit_det[nd];
     if (d < 0) return;
     const int64_t pos = offs[(int64_t)d * n + i];
-    for (int sub = 0; sub < nsub; ++sub) {
-        for (int c = 0; c < 9; ++c) out[(pos + sub) * 9 + c] = hit[((int64_t)nd * nsub + sub) * 9 + c];
-        out_node[pos + sub] = (int32_t)i;
-    }
+    out[pos * 9 + k] = hit[(int64_t)nd * width + k];
+    if (k % 9 == 0) out_node[pos + k / 9] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------ host-side objects
@@ -1143,14 +1165,35 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     const unsigned nb = (unsigned)((n_nodes + 255) / 256);
     if (n_nodes > 0) hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, stream, (int32_t*)R->order.p, n_nodes);
     if (n_nodes > n) {
-        DevBuf keys_out, vals_out, tmp;
-        if ((rc = keys_out.alloc((size_t)n_nodes * 8)) || (rc = vals_out.alloc((size_t)n_nodes * 4))) return rc;
+        auto bits_for = [](unsigned long long v) {  // bits needed to hold values 0..v
+            int b = 0;
+            while (b < 64 && (v >> b)) ++b;
+            return b;
+        };
+        const int max_depth = (int)std::min<unsigned long long>(h_ctr.max_depth, 26);  // path has one bit per level (26 kept)
+        const int bits_path = max_depth, bits_depth = bits_for(h_ctr.max_depth), bits_root = bits_for((unsigned long long)std::max<int64_t>(n - 1, 0));
+        const int bits = bits_root + bits_depth + bits_path;
+        const bool narrow = bits <= 32;
+        DevBuf keys_in, keys_out, vals_out, tmp;
+        if ((rc = keys_in.alloc((size_t)n_nodes * (narrow ? 4 : 8))) || (rc = keys_out.alloc((size_t)n_nodes * (narrow ? 4 : 8))) ||
+            (rc = vals_out.alloc((size_t)n_nodes * 4)))
+            return rc;
+        hipLaunchKernelGGL(pack_keys_kernel, dim3(nb), dim3(256), 0, stream, (const unsigned long long*)R->n_key.p, n_nodes, bits_depth, bits_path,
+                           narrow ? (uint32_t*)keys_in.p : nullptr, narrow ? nullptr : (unsigned long long*)keys_in.p);
         size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)R->n_key.p, (unsigned long long*)keys_out.p,
-                                                   (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, 64, stream));
-        if ((rc = tmp.alloc(tmp_bytes))) return rc;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)R->n_key.p, (unsigned long long*)keys_out.p,
-                                                   (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, 64, stream));
+        if (narrow) {
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
+                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+            if ((rc = tmp.alloc(tmp_bytes))) return rc;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
+                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+        } else {
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
+                                                       (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+            if ((rc = tmp.alloc(tmp_bytes))) return rc;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
+                                                       (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         std::swap(R->order.p, vals_out.p);
         std::swap(R->order.bytes, vals_out.bytes);
@@ -1171,14 +1214,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
         // per-detector offsets = scan value at the start of each detector's segment; total = last offs + last flag
+        if (nd + 1 > 1024) return fail(BMO_ERR_UNSUPPORTED, "more than 1023 detectors");
+        DevBuf d_off;
+        if ((rc = d_off.alloc((size_t)(nd + 1) * 4))) return rc;
+        hipLaunchKernelGGL(hit_offsets_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)offs.p, (const int32_t*)flags.p, n_nodes, nd, (int32_t*)d_off.p);
         std::vector<int32_t> h_off(nd + 1, 0);
-        for (int d = 0; d < nd; ++d)
-            HIP_TRY(hipMemcpyAsync(&h_off[d], (const int32_t*)offs.p + (int64_t)d * n_nodes, 4, hipMemcpyDeviceToHost, stream));
-        int32_t last_off = 0, last_flag = 0;
-        HIP_TRY(hipMemcpyAsync(&last_off, (const int32_t*)offs.p + tot - 1, 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&last_flag, (const int32_t*)flags.p + tot - 1, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_off.data(), d_off.p, (size_t)(nd + 1) * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        h_off[nd] = last_off + last_flag;
         const int64_t total = h_off[nd];
         for (int d = 0; d < nd; ++d) {
             R->det_offset[d] = h_off[d];
@@ -1186,7 +1228,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
         if ((rc = R->det_data.alloc((size_t)std::max<int64_t>(total, 1) * 72)) || (rc = R->det_node.alloc((size_t)std::max<int64_t>(total, 1) * 4)))
             return rc;
-        hipLaunchKernelGGL(hit_gather_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
+        const int64_t gather_threads = n_nodes * 9 * nsub;
+        hipLaunchKernelGGL(hit_gather_kernel, dim3((unsigned)((gather_threads + 255) / 256)), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
                            (const double*)R->n_hit.p, n_nodes, nsub, (const int32_t*)offs.p, (double*)R->det_data.p,
                            (int32_t*)R->det_node.p);
         HIP_TRY(hipStreamSynchronize(stream));
