@@ -164,6 +164,8 @@ struct StepParams {
     uint32_t blob_bytes;
     int32_t use_lds;
     Chunk cur, nxt;
+    Chunk inner[3];   // in-place levels 1..n_fuse-1 of this launch (Beam kernels; capacity >= cur.count, same slot numbering as cur)
+    int32_t n_fuse;   // bounces per launch, 1..4
     Counters* ctr;
     unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
     NodeArrays nodes;
@@ -275,6 +277,11 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
     }
 }
 
+// One launch advances every active beam by up to P.n_fuse bounces.  Bounce 0 reads its records from P.cur; a lane that goes
+// on writes its next record IN PLACE (same slot j) into P.inner[b] and traces it in the same launch — no compaction, no host
+// round trip, the ray stays in registers; lanes that ended leave an invalid record (node = -1) in the inner chunks.  The fused
+// loop ends for a whole workgroup when one of its lanes splits (children need the block-wide slot allocation below) or when none
+// goes on.  Survivors of the last fused bounce and beam-splitter children are compacted into P.nxt as before.
 template <int KIND, bool LDS, bool ASPH, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -283,104 +290,18 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t m = P.cur.count, cap = P.cur.cap;
+    const int64_t m = P.cur.count;
     const bool valid = j < m;
 
-    bool survive = false, split = false;
-    int32_t node = -1, k = 0, li = 0;
-    StepOut o;
-    o.outcome = OUT_MISS;
-    o.status = 0;
-    o.hint_obj = o.hint_shape = -1;
-    o.det_slot = -1;
+    // A lane carries nothing but `alive` from one fused bounce to the next: it writes its next record and reads it back at the
+    // top of the next iteration (its own store, served by L1/L2) — keeping the ray in registers across the march instead costs
+    // ~300 B/lane of scratch spills.
+    bool alive = valid;
     uint32_t calls = 0;
-    double opl_next = 0.0, lambda = 0.0;
-    RetraceLane rt;
-    bool still = false, old_kids = false;
-
-    if (valid) {
-        const double* D = P.cur.d;
-        int32_t* I = P.cur.i;
-        node = I[I_NODE * cap + j];
-        k = I[I_K * cap + j];
-        const int32_t flags = I[I_FLAGS * cap + j];
-        RayS ray;
-        ray.pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
-        ray.dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
-        ray.n = D[6 * cap + j];
-        if (KIND == BMO_BEAM_POLARIZED)
-            for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
-        const double opl_acc = D[L::OPL * cap + j];
-        li = P.nodes.li[node];
-        lambda = P.nodes.lambda[node];
-        Hit X;
-        X.shape = -1;
-        X.obj = -1;
-        X.t = kinf();
-        X.n = {0, 0, 0};
-        int status = 0;
-        int32_t hobj = I[I_HOBJ * cap + j], hshape = I[I_HSHAPE * cap + j];
-        if (RETR) {
-            rt = retrace_lane(P, node, k);
-            if (rt.old >= 0 && !rt.probe) hobj = hshape = -1;
-        }
-        if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
-            status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
-        } else {
-            // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
-            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
-            X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hobj, hshape, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
-            if (X.shape < 0) {
-                status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
-            } else {
-                interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
-                status = o.status;
-                if (o.outcome == OUT_CONTINUE) {
-                    survive = true;
-                    opl_next = opl_acc + X.t * ray.n;
-                } else if (o.outcome == OUT_SPLIT) {
-                    split = true;
-                    status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
-                    opl_next = opl_acc + X.t * ray.n;
-                } else {
-                    status |= BMO_NODE_STOPPED;
-                }
-            }
-        }
-        // intersection part of this record
-        double* Dw = P.cur.d;
-        Dw[7 * cap + j] = X.t;
-        Dw[8 * cap + j] = X.n.x;
-        Dw[9 * cap + j] = X.n.y;
-        Dw[10 * cap + j] = X.n.z;
-        I[I_OBJ * cap + j] = X.obj;
-        I[I_SHAPE * cap + j] = X.shape;
-        if (RETR) {
-            still = rt.old >= 0 && rt.probe && !rt.missed;  // the stored path held at this ray
-            old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
-            if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
-            if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
-        }
-        if (!survive) {  // node ends here
-            P.nodes.nseg[node] = k + 1;
-            P.nodes.status[node] = status;
-            if (o.det_slot >= 0) {
-                P.nodes.hit_det[node] = o.det_slot;
-                for (int c = 0; c < 9; ++c) P.nodes.hit[(int64_t)node * 9 + c] = o.det[c];
-            }
-        }
-    }
-
-    // ---- wave-level compaction: survivors first, then 2 children per splitting lane
-    const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
-    const int64_t ncap = P.nxt.cap;
-    auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
-        if (slot >= ncap) {
-            atomicAdd(&P.ctr->overflow, 1ull);
-            return;
-        }
-        double* D = P.nxt.d;
-        int32_t* I = P.nxt.i;
+    auto write_ray = [&](const Chunk& C, int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
+        const int64_t ncap = C.cap;
+        double* D = C.d;
+        int32_t* I = C.i;
         D[0 * ncap + slot] = r.pos.x;
         D[1 * ncap + slot] = r.pos.y;
         D[2 * ncap + slot] = r.pos.z;
@@ -400,42 +321,177 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         I[I_HSHAPE * ncap + slot] = hs;
         I[I_FLAGS * ncap + slot] = fl;
     };
-    if (survive) {
-        const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
-        int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
-        int32_t ho = o.hint_obj, hs = o.hint_shape;
-        if (RETR && still) {
-            if (k + 1 < rt.old_n) fl = 0;  // replace!: the next stored ray is re-walked whatever r_max says
-            else ho = hs = -1;            // push!, then trace_system! starts over without a hint
+
+    int b = 0;  // fused bounce index: records of bounce b live in C = (b == 0 ? P.cur : P.inner[b - 1]) at slot j
+    for (;;) {
+        const Chunk C = b == 0 ? P.cur : P.inner[b - 1];
+        bool survive = false, split = false, still = false, old_kids = false;
+        double opl_next = 0.0;
+        StepOut o;
+        o.outcome = OUT_MISS;
+        o.status = 0;
+        o.hint_obj = o.hint_shape = -1;
+        o.det_slot = -1;
+        RetraceLane rt;
+        int32_t node = -1, k = 0, li = 0, flags = 0, hobj = -1, hshape = -1;
+        RayS ray;
+        double opl_acc = 0.0, lambda = 0.0;
+        if (alive) {
+            const int64_t cap = C.cap;
+            const double* D = C.d;
+            const int32_t* I = C.i;
+            node = I[I_NODE * cap + j];
+            k = I[I_K * cap + j];
+            flags = I[I_FLAGS * cap + j];
+            ray.pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
+            ray.dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+            ray.n = D[6 * cap + j];
+            if (KIND == BMO_BEAM_POLARIZED)
+                for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
+            opl_acc = D[L::OPL * cap + j];
+            hobj = I[I_HOBJ * cap + j];
+            hshape = I[I_HSHAPE * cap + j];
+            li = P.nodes.li[node];
+            lambda = P.nodes.lambda[node];
         }
-        write_next(slot, o.next, node, k + 1, ho, hs, fl, opl_next);
-    }
-    if (split) {
-        const int r = prefix_rank(al.m_split);
-        const int64_t slot = (int64_t)al.child_base + 2 * r;
-        const int64_t cn = (int64_t)al.node_base + 2 * r;
-        if (cn + 1 < P.nodes.cap) {
-            const unsigned long long pkey = P.nodes.key[node];
-            const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
-            atomicMax(&P.ctr->max_depth, depth + 1ull);
-            for (int w = 0; w < 2; ++w) {
-                const int64_t c = cn + w;
-                P.nodes.root[c] = (int32_t)root;
-                P.nodes.parent[c] = node;
-                P.nodes.nseg[c] = 1;
-                P.nodes.status[c] = 0;
-                P.nodes.li[c] = li;
-                P.nodes.lambda[c] = lambda;
-                P.nodes.hit_det[c] = -1;
-                P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
-                if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
+        // header of the record that follows a surviving bounce: r_max flag and hint, with the retrace overrides
+        auto next_header = [&](int32_t& fl, int32_t& ho, int32_t& hs) {
+            fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+            ho = o.hint_obj;
+            hs = o.hint_shape;
+            if (RETR && still) {
+                if (k + 1 < rt.old_n) fl = 0;  // replace!: the next stored ray is re-walked whatever r_max says
+                else ho = hs = -1;            // push!, then trace_system! starts over without a hint
             }
-            const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
-            write_next(slot, o.next, (int32_t)cn, 0, -1, -1, fl, opl_next);
-            write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, fl, opl_next);
-        } else {
-            atomicAdd(&P.ctr->overflow, 1ull);
+        };
+        if (alive) {
+            const int64_t cap = C.cap;
+            Hit X;
+            X.shape = -1;
+            X.obj = -1;
+            X.t = kinf();
+            X.n = {0, 0, 0};
+            int status = 0;
+            o.det_slot = -1;
+            int32_t ho = hobj, hs = hshape;
+            if (RETR) {
+                rt = retrace_lane(P, node, k);
+                if (rt.old >= 0 && !rt.probe) ho = hs = -1;
+            }
+            if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
+                status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
+            } else {
+                // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
+                ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+                X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, ho, hs, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                if (X.shape < 0) {
+                    status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
+                } else {
+                    interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
+                    status = o.status;
+                    if (o.outcome == OUT_CONTINUE) {
+                        survive = true;
+                        opl_next = opl_acc + X.t * ray.n;
+                    } else if (o.outcome == OUT_SPLIT) {
+                        split = true;
+                        status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                        opl_next = opl_acc + X.t * ray.n;
+                    } else {
+                        status |= BMO_NODE_STOPPED;
+                    }
+                }
+            }
+            // intersection part of this record
+            double* Dw = C.d;
+            int32_t* Iw = C.i;
+            Dw[7 * cap + j] = X.t;
+            Dw[8 * cap + j] = X.n.x;
+            Dw[9 * cap + j] = X.n.y;
+            Dw[10 * cap + j] = X.n.z;
+            Iw[I_OBJ * cap + j] = X.obj;
+            Iw[I_SHAPE * cap + j] = X.shape;
+            if (RETR) {
+                still = rt.old >= 0 && rt.probe && !rt.missed;  // the stored path held at this ray
+                old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
+                if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+                if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
+            }
+            if (!survive) {  // node ends here
+                P.nodes.nseg[node] = k + 1;
+                P.nodes.status[node] = status;
+                if (o.det_slot >= 0) {
+                    P.nodes.hit_det[node] = o.det_slot;
+                    for (int c = 0; c < 9; ++c) P.nodes.hit[(int64_t)node * 9 + c] = o.det[c];
+                }
+            }
         }
+        // block-uniform decisions (every thread of the workgroup reaches these barriers)
+        bool go_on = b + 1 < P.n_fuse;
+        if (go_on) go_on = !__syncthreads_or(split ? 1 : 0);
+        if (go_on) go_on = __syncthreads_or(survive ? 1 : 0) != 0;
+        if (go_on) {
+            // go on in place: the next record of a surviving lane is written to the same slot of the next inner chunk
+            const Chunk N = P.inner[b];
+            if (valid) {
+                if (alive && survive) {
+                    int32_t fl, ho, hs;
+                    next_header(fl, ho, hs);
+                    write_ray(N, j, o.next, node, k + 1, ho, hs, fl, opl_next);
+                } else {
+                    N.i[I_NODE * N.cap + j] = -1;  // no record of this beam at this level
+                    alive = false;
+                }
+            }
+            b += 1;
+            continue;
+        }
+        // ---- last fused bounce of this workgroup (kept inside the loop so that o.next / o.refl die here instead of staying live
+        //      across the march of the next iteration): mark the levels not reached, then compact into the next launch's chunk
+        if (valid)
+            for (int bb = b + 1; bb < P.n_fuse; ++bb) P.inner[bb - 1].i[I_NODE * P.inner[bb - 1].cap + j] = -1;
+        const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
+        const int64_t ncap = P.nxt.cap;
+        auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
+            if (slot >= ncap) {
+                atomicAdd(&P.ctr->overflow, 1ull);
+                return;
+            }
+            write_ray(P.nxt, slot, r, nd, kk, ho, hs, fl, opl);
+        };
+        if (survive) {  // survivors first
+            const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
+            int32_t fl, ho, hs;
+            next_header(fl, ho, hs);
+            write_next(slot, o.next, node, k + 1, ho, hs, fl, opl_next);
+        }
+        if (split) {  // then 2 children per splitting lane
+            const int r = prefix_rank(al.m_split);
+            const int64_t slot = (int64_t)al.child_base + 2 * r;
+            const int64_t cn = (int64_t)al.node_base + 2 * r;
+            if (cn + 1 < P.nodes.cap) {
+                const unsigned long long pkey = P.nodes.key[node];
+                const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+                atomicMax(&P.ctr->max_depth, depth + 1ull);
+                for (int w = 0; w < 2; ++w) {
+                    const int64_t c = cn + w;
+                    P.nodes.root[c] = (int32_t)root;
+                    P.nodes.parent[c] = node;
+                    P.nodes.nseg[c] = 1;
+                    P.nodes.status[c] = 0;
+                    P.nodes.li[c] = li;
+                    P.nodes.lambda[c] = lambda;
+                    P.nodes.hit_det[c] = -1;
+                    P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                    if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
+                }
+                const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
+                write_next(slot, o.next, (int32_t)cn, 0, -1, -1, fl, opl_next);
+                write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, fl, opl_next);
+            } else {
+                atomicAdd(&P.ctr->overflow, 1ull);
+            }
+        }
+        return;
     }
 }
 
@@ -654,6 +710,7 @@ __global__ void old_obj_scatter_kernel(Chunk c, const int32_t* __restrict__ rec_
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
     const int32_t node = c.i[I_NODE * c.cap + j], k = c.i[I_K * c.cap + j];
+    if (node < 0) return;  // hole of a fused level
     rec_obj[(int64_t)rec_start[node] + k] = c.i[I_OBJ * c.cap + j];
 }
 __global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key, int64_t n, int32_t* __restrict__ first_child) {
@@ -1098,9 +1155,22 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     int64_t n_nodes = n;
     double kernel_ms = 0;
     int steps = 0;
+    // bounces per launch (Beam kernels): fewer launches, host round trips and scene stagings; holes instead of compaction inside a
+    // launch.  BMO_FUSE=1 restores one launch per bounce level.
+    int fuse_max = 1;
+    if (KIND != BMO_BEAM_GAUSSIAN) {
+        fuse_max = 4;
+        if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(4, atoi(e)));
+    }
+    double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
     while (cur.count > 0) {
         const int64_t m = cur.count;
-        Chunk nxt;
+        const int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
+        Chunk nxt, inner[3];
+        for (int q = 0; q + 1 < n_fuse; ++q) {
+            if ((rc = new_chunk(m, inner[q]))) return rc;
+            inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
+        }
         if ((rc = new_chunk(has_split ? 2 * m : m, nxt))) return rc;
         if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
         StepParams P;
@@ -1109,6 +1179,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.use_lds = use_lds;
         P.cur = cur;
         P.nxt = nxt;
+        for (int q = 0; q < 3; ++q) P.inner[q] = q + 1 < n_fuse ? inner[q] : Chunk{nullptr, nullptr, 0, 0};
+        P.n_fuse = n_fuse;
         P.ctr = d_ctr;
         P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
         P.nodes = node_arrays();
@@ -1134,7 +1206,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
         R->chunks.push_back(cur);
+        for (int q = 0; q + 1 < n_fuse; ++q) R->chunks.push_back(inner[q]);
         shrink_last(nxt, (int64_t)produced);
+        keep_ratio = (double)std::min<unsigned long long>(produced, (unsigned long long)m) / (double)m;
         n_nodes = (int64_t)h_ctr.node_count;
         cur = nxt;
     }
@@ -1156,9 +1230,20 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     R->n_steps = steps;
     R->kernel_ms = kernel_ms;
-    int64_t nrec = 0;
-    for (auto& c : R->chunks) nrec += c.count;
-    R->n_records = nrec;
+    {   // segments = sum of the beams' segment counts (chunk counts include the holes of fused levels)
+        DevBuf d_sum, tmp;
+        size_t tmp_bytes = 0;
+        long long h_sum = 0;
+        if (n_nodes > 0) {
+            if ((rc = d_sum.alloc(8))) return rc;
+            HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum.p, (int)n_nodes, stream));
+            if ((rc = tmp.alloc(tmp_bytes))) return rc;
+            HIP_TRY(hipcub::DeviceReduce::Sum(tmp.p, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum.p, (int)n_nodes, stream));
+            HIP_TRY(hipMemcpyAsync(&h_sum, d_sum.p, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        R->n_records = (int64_t)h_sum;
+    }
 
     // ---- canonical node order (bundle order x BFS order): sort by (root, depth, path)
     if ((rc = R->order.alloc((size_t)std::max<int64_t>(n_nodes, 1) * 4))) return rc;
@@ -1535,6 +1620,7 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
             if ((rc = dl(cd, c.d, (size_t)r->nd * c.cap)) || (rc = dl(ci, c.i, (size_t)NI * c.cap))) return rc;
             for (int64_t j = 0; j < c.count; ++j) {
                 const int32_t nd = ci[I_NODE * c.cap + j], k = ci[I_K * c.cap + j];
+                if (nd < 0) continue;  // hole of a fused level
                 const int64_t dst = (int64_t)r->h_first_rec[rank[nd]] + k;
                 for (int p = 0; p < P; ++p) r->h_rec[(size_t)p * nr + dst] = cd[(size_t)p * c.cap + j];
                 r->h_rec_obj[dst] = ci[I_OBJ * c.cap + j];
