@@ -336,7 +336,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         int32_t node = -1, k = 0, li = 0, flags = 0, hobj = -1, hshape = -1;
         RayS ray;
         double opl_acc = 0.0, lambda = 0.0;
-        if (alive) {
+        if (alive) {  // what the march needs; the rest of the record is read after it (fewer registers live across the march)
             const int64_t cap = C.cap;
             const double* D = C.d;
             const int32_t* I = C.i;
@@ -345,14 +345,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             flags = I[I_FLAGS * cap + j];
             ray.pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
             ray.dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
-            ray.n = D[6 * cap + j];
-            if (KIND == BMO_BEAM_POLARIZED)
-                for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
-            opl_acc = D[L::OPL * cap + j];
             hobj = I[I_HOBJ * cap + j];
             hshape = I[I_HSHAPE * cap + j];
-            li = P.nodes.li[node];
-            lambda = P.nodes.lambda[node];
         }
         // header of the record that follows a surviving bounce: r_max flag and hint, with the retrace overrides
         auto next_header = [&](int32_t& fl, int32_t& ho, int32_t& hs) {
@@ -387,6 +381,15 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 if (X.shape < 0) {
                     status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 } else {
+                    {   // the interaction's share of the record
+                        const double* D = C.d;
+                        ray.n = D[6 * cap + j];
+                        if (KIND == BMO_BEAM_POLARIZED)
+                            for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
+                        opl_acc = D[L::OPL * cap + j];
+                        li = P.nodes.li[node];
+                        lambda = P.nodes.lambda[node];
+                    }
                     interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
                     status = o.status;
                     if (o.outcome == OUT_CONTINUE) {
