@@ -993,7 +993,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             if (c.first == device) ctxp = c.second.get();
         if (!ctxp) {
             auto nc = std::make_unique<DevCtx>();
-            HIP_TRY(hipStreamCreate(&nc->stream));
+            // non-blocking: no implicit synchronisation with the NULL stream, so a collective or copy another library has in flight
+            // there (RCCL all-gather of the previous solve's hits) overlaps this solve
+            HIP_TRY(hipStreamCreateWithFlags(&nc->stream, hipStreamNonBlocking));
             for (int q = 0; q < 4; ++q) HIP_TRY(hipEventCreate(&nc->ev[q]));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&nc->pinned), sizeof(Counters), hipHostMallocDefault));
             ctxp = nc.get();

@@ -41,25 +41,35 @@ def all_gather_hits(local_hits, group=None, async_op=False):
     buffers padded to the maximum count, trimmed and concatenated in rank order.  With async_op the payload collective is
     left in flight (PendingGather) so that it overlaps the next trace; call .wait() before using the result.
     """
-    world = dist.get_world_size(group)
-    dev = local_hits.device
-    width = local_hits.shape[1]
-    cnt = torch.tensor([local_hits.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = torch.cat(counts).cpu()
-    mx = max(int(counts.max()), 1)
-    buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
-    buf[: local_hits.shape[0]] = local_hits
-    if dist.get_backend(group) == "nccl":  # one contiguous receive buffer: no per-rank copy kernels after the ring all-gather
-        flat = torch.empty((world * mx, width), dtype=torch.float64, device=dev)
-        work = dist.all_gather_into_tensor(flat, buf, group=group, async_op=True)
-        outs = [flat[r * mx:(r + 1) * mx] for r in range(world)]
-    else:
-        outs = [torch.empty_like(buf) for _ in range(world)]
-        work = dist.all_gather(outs, buf, group=group, async_op=True)
-    pending = PendingGather(work, outs, counts)
+    pending = all_gather_hit_lists([local_hits], group)[0]
     return pending if async_op else pending.wait()
+
+
+def all_gather_hit_lists(payloads, group=None):
+    """The exchange step for several detectors at once: ONE collective for all their counts, then one payload all-gather per
+    detector left in flight.  payloads: list of [count_d, width_d] float64 tensors.  Returns a list of PendingGather."""
+    world = dist.get_world_size(group)
+    dev = payloads[0].device
+    cnt = torch.tensor([p.shape[0] for p in payloads], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt, group=group)
+    allc = torch.stack(allc).cpu()  # [world, nd]
+    out = []
+    for d, p in enumerate(payloads):
+        counts = allc[:, d].contiguous()
+        mx = max(int(counts.max()), 1)
+        width = p.shape[1]
+        buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
+        buf[: p.shape[0]] = p
+        if dist.get_backend(group) == "nccl":
+            flat = torch.empty((world * mx, width), dtype=torch.float64, device=dev)
+            work = dist.all_gather_into_tensor(flat, buf, group=group, async_op=True)
+            outs = [flat[r * mx:(r + 1) * mx] for r in range(world)]
+        else:
+            outs = [torch.empty_like(buf) for _ in range(world)]
+            work = dist.all_gather(outs, buf, group=group, async_op=True)
+        out.append(PendingGather(work, outs, counts))
+    return out
 
 
 def all_reduce_field(field, group=None):

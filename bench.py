@@ -115,11 +115,14 @@ def main():
             # (the columns the detector keeps), left in flight so that it overlaps the NEXT trace (separate RCCL stream);
             # the previous step's exchange is completed first, and the last one inside the timed region (sync()).
             finish_exchange()
+            payloads = []
             for s in range(n_det):
                 local = torch.empty((counts[s], 9), dtype=torch.float64, device="cuda")
                 eng.result_copy_hits(res, s, local.data_ptr(), counts[s])
                 payload = local[:, : det_width[s]].contiguous()
-                in_flight.append(bd.all_gather_hits(payload if backend == "nccl" else payload.cpu(), async_op=True))
+                payloads.append(payload if backend == "nccl" else payload.cpu())
+            if payloads:
+                in_flight.extend(bd.all_gather_hit_lists(payloads))
         stats = dict(kernel_ms=kms, total_ms=tms, launches=nl, hits=counts)
         return res, stats
 
@@ -197,7 +200,7 @@ def main():
                             "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors; r_max=100; full segment log kept",
                 "rays_per_gpu": n_local, "elements": scene.n_objects, "shapes": len(scene.shape_list),
                 "segments_per_step": int(traced_all), "beam_nodes": int(nnodes), "detector_hits": int(hits_all),
-                "intersect3d_calls_per_step": int(calls_all), "parallelism": f"ray-shard x{world}" + (" + RCCL all-gather of detector hits" if world > 1 else ""),
+                "intersect3d_calls_per_step": int(calls_all), "parallelism": f"ray-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all-gather of detector hits" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

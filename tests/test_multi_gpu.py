@@ -112,3 +112,29 @@ def test_sharded_photodetector_field_all_reduce(tmp_path):
     world = 2
     mp.spawn(_pd_worker, args=(world, _free_port(), 48, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _lists_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmo_amd import distributed as bd
+
+    # two detectors with different widths and ragged (one empty) per-rank counts
+    a = torch.arange((3 if rank == 0 else 0) * 2, dtype=torch.float64).reshape(-1, 2) + 100 * rank
+    b = torch.arange((2 + rank) * 9, dtype=torch.float64).reshape(-1, 9) + 1000 * rank
+    pend = bd.all_gather_hit_lists([a, b])
+    (ha, ca), (hb, cb) = [p.wait() for p in pend]
+    assert ca.tolist() == [3, 0] and cb.tolist() == [2, 3]
+    assert ha.shape == (3, 2) and hb.shape == (5, 9)
+    assert torch.equal(hb[:2], torch.arange(18, dtype=torch.float64).reshape(2, 9)) and torch.equal(hb[2:], torch.arange(27, dtype=torch.float64).reshape(3, 9) + 1000)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_hit_lists(tmp_path):
+    mp.spawn(_lists_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
