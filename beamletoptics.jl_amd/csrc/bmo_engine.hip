@@ -767,6 +767,20 @@ __global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, 
     if (k % 9 == 0) out_node[pos + k / 9] = (int32_t)i;
 }
 
+// Segment log -> the ABI's node-major order (bmo_trace_result_view.rec): record j of a step chunk goes to first_rec(node) + k.
+// Done in HBM so that the host receives ONE contiguous copy per table instead of re-ordering 10^7 records itself.
+__global__ void order_records_kernel(Chunk c, int planes, const int32_t* __restrict__ dst_base, int64_t nr, double* __restrict__ rec,
+                                     int32_t* __restrict__ obj, int32_t* __restrict__ shape) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c.count) return;
+    const int32_t nd = c.i[I_NODE * c.cap + j];
+    if (nd < 0) return;  // hole of a fused level
+    const int64_t dst = (int64_t)dst_base[nd] + c.i[I_K * c.cap + j];
+    for (int p = 0; p < planes; ++p) rec[(int64_t)p * nr + dst] = c.d[(int64_t)p * c.cap + j];
+    obj[dst] = c.i[I_OBJ * c.cap + j];
+    shape[dst] = c.i[I_SHAPE * c.cap + j];
+}
+
 // ------------------------------------------------------------------ host-side objects
 // Device memory pool: hipMalloc/hipFree of the multi-GB segment log cost more than the trace itself, so
 // freed blocks are kept per device and reused by the next trace (same sizes every call for a fixed batch).
@@ -849,6 +863,64 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+// Page-locked host memory for the tables bmo_result_view hands out: a D2H copy into pinned memory runs at PCIe speed, into
+// pageable memory at a fraction of it.  Pinning costs more than the copy, so freed blocks are kept (up to a cap) and reused
+// by the next view of a similar size.
+constexpr size_t HOST_POOL_CAP = (size_t)16 << 30;
+std::mutex g_hpool_mu;
+std::vector<PoolBlock> g_hpool;
+size_t g_hpool_bytes = 0;
+
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b) {
+        release();
+        if (b == 0) b = 16;
+        {
+            std::lock_guard<std::mutex> lk(g_hpool_mu);
+            int best = -1;
+            for (int i = 0; i < (int)g_hpool.size(); ++i) {
+                const PoolBlock& k = g_hpool[i];
+                if (k.bytes < b || k.bytes > b + b / 4 + 4096) continue;
+                if (best < 0 || k.bytes < g_hpool[best].bytes) best = i;
+            }
+            if (best >= 0) {
+                p = g_hpool[best].p;
+                bytes = g_hpool[best].bytes;
+                g_hpool_bytes -= bytes;
+                g_hpool.erase(g_hpool.begin() + best);
+                return BMO_OK;
+            }
+        }
+        if (hipHostMalloc(&p, b, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            return fail(BMO_ERR_OOM, "hipHostMalloc failed");
+        }
+        bytes = b;
+        return BMO_OK;
+    }
+    void release() {
+        if (!p) return;
+        std::unique_lock<std::mutex> lk(g_hpool_mu);
+        if (g_hpool_bytes + bytes <= HOST_POOL_CAP) {
+            g_hpool.push_back({p, bytes, 0});
+            g_hpool_bytes += bytes;
+        } else {
+            lk.unlock();
+            (void)hipHostFree(p);
+        }
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+    ~HostBuf() { release(); }
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+};
+
 }  // namespace
 
 struct bmo_scene {
@@ -899,8 +971,9 @@ struct bmo_trace_result {
     std::vector<int64_t> det_count, det_offset;
     // host views (filled by bmo_result_view)
     bool viewed = false;
-    std::vector<int32_t> h_root, h_parent, h_first_child, h_first_rec, h_nseg, h_status, h_rec_obj, h_rec_shape, h_det_node;
-    std::vector<double> h_aux, h_rec, h_det;
+    std::vector<int32_t> h_root, h_parent, h_first_child, h_first_rec, h_nseg, h_status;
+    std::vector<double> h_aux;
+    HostBuf h_rec, h_rec_obj, h_rec_shape, h_det, h_det_node;  // the large tables: pinned
 };
 
 namespace {
@@ -1557,7 +1630,7 @@ int bmo_result_copy_hits(bmo_trace_result* r, int32_t det, double* dst, int64_t 
     const int64_t n = std::min<int64_t>(max_hits, r->det_count[det]);
     if (n <= 0) return BMO_OK;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipMemcpy(dst, static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det], (size_t)n * 72, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(dst, static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det], (size_t)n * 72, hipMemcpyDefault));
     return BMO_OK;
 }
 
@@ -1615,26 +1688,35 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
         }
         if (acc != nr) return fail(BMO_ERR_INTERNAL, "segment count mismatch");
         const int P = r->abi_planes;
-        r->h_rec.assign((size_t)P * nr, 0.0);
-        r->h_rec_obj.assign(nr, -1);
-        r->h_rec_shape.assign(nr, -1);
-        std::vector<double> cd;
-        std::vector<int32_t> ci;
-        for (const Chunk& c : r->chunks) {
-            if (c.count == 0) continue;
-            if ((rc = dl(cd, c.d, (size_t)r->nd * c.cap)) || (rc = dl(ci, c.i, (size_t)NI * c.cap))) return rc;
-            for (int64_t j = 0; j < c.count; ++j) {
-                const int32_t nd = ci[I_NODE * c.cap + j], k = ci[I_K * c.cap + j];
-                if (nd < 0) continue;  // hole of a fused level
-                const int64_t dst = (int64_t)r->h_first_rec[rank[nd]] + k;
-                for (int p = 0; p < P; ++p) r->h_rec[(size_t)p * nr + dst] = cd[(size_t)p * c.cap + j];
-                r->h_rec_obj[dst] = ci[I_OBJ * c.cap + j];
-                r->h_rec_shape[dst] = ci[I_SHAPE * c.cap + j];
-            }
-        }
         int64_t tot = 0;
         for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
-        if ((rc = dl(r->h_det, r->det_data.p, (size_t)tot * 9)) || (rc = dl(r->h_det_node, r->det_node.p, (size_t)tot))) return rc;
+        if ((rc = r->h_rec.alloc((size_t)P * nr * 8)) || (rc = r->h_rec_obj.alloc((size_t)nr * 4)) || (rc = r->h_rec_shape.alloc((size_t)nr * 4)) ||
+            (rc = r->h_det.alloc((size_t)tot * 72)) || (rc = r->h_det_node.alloc((size_t)tot * 4)))
+            return rc;
+        if (nr > 0) {
+            // re-order on the device, then one copy per table
+            std::vector<int32_t> dst_base(nn);
+            for (int64_t i = 0; i < nn; ++i) dst_base[order[i]] = r->h_first_rec[i];
+            DevBuf d_base, d_rec, d_obj, d_shape;
+            if ((rc = d_base.alloc((size_t)nn * 4)) || (rc = d_rec.alloc((size_t)P * nr * 8)) || (rc = d_obj.alloc((size_t)nr * 4)) || (rc = d_shape.alloc((size_t)nr * 4)))
+                return rc;
+            HIP_TRY(hipMemcpy(d_base.p, dst_base.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemset(d_rec.p, 0, (size_t)P * nr * 8));
+            HIP_TRY(hipMemset(d_obj.p, 0xFF, (size_t)nr * 4));
+            HIP_TRY(hipMemset(d_shape.p, 0xFF, (size_t)nr * 4));
+            for (const Chunk& c : r->chunks)
+                if (c.count > 0)
+                    hipLaunchKernelGGL(order_records_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, 0, c, P, (const int32_t*)d_base.p, nr,
+                                       (double*)d_rec.p, (int32_t*)d_obj.p, (int32_t*)d_shape.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(r->h_rec.p, d_rec.p, (size_t)P * nr * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_rec_obj.p, d_obj.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_rec_shape.p, d_shape.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        }
+        if (tot > 0) {
+            HIP_TRY(hipMemcpy(r->h_det.p, r->det_data.p, (size_t)tot * 72, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_det_node.p, r->det_node.p, (size_t)tot * 4, hipMemcpyDeviceToHost));
+        }
         r->viewed = true;
     }
     std::memset(v, 0, sizeof *v);
@@ -1653,13 +1735,13 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
     v->node_nseg = r->h_nseg.data();
     v->node_status = r->h_status.data();
     v->node_aux = r->h_aux.data();
-    v->rec_obj = r->h_rec_obj.data();
-    v->rec_shape = r->h_rec_shape.data();
-    v->rec = r->h_rec.data();
+    v->rec_obj = r->h_rec_obj.as<int32_t>();
+    v->rec_shape = r->h_rec_shape.as<int32_t>();
+    v->rec = r->h_rec.as<double>();
     v->det_count = r->det_count.data();
     v->det_offset = r->det_offset.data();
-    v->det_node = r->h_det_node.data();
-    v->det_data = r->h_det.data();
+    v->det_node = r->h_det_node.as<int32_t>();
+    v->det_data = r->h_det.as<double>();
     return BMO_OK;
 }
 

@@ -282,9 +282,11 @@ int bmo_trace_device(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_
 /* Device pointers of the ordered detector hit buffers (for RCCL all-gather):
  * data = [count][9] doubles on the device the trace ran on.                        */
 int bmo_result_device_hits(bmo_trace_result* res, int32_t detector, const double** data, int64_t* count);
-/* Copies up to max_hits ordered hits (9 doubles each) of one detector into dst, a DEVICE pointer on the
- * device the trace ran on (e.g. the data_ptr of a torch tensor used as RCCL all-gather input).   */
-int bmo_result_copy_hits(bmo_trace_result* res, int32_t detector, double* dst_device, int64_t max_hits);
+/* Copies up to max_hits ordered hits (9 doubles each) of one detector into dst: a pointer on the device the
+ * trace ran on (e.g. the data_ptr of a torch tensor used as RCCL all-gather input) or host memory (page-locked
+ * memory copies at PCIe speed; pageable memory works, slower) - the Spotdetector read-out that does not need
+ * the segment log.                                                                                          */
+int bmo_result_copy_hits(bmo_trace_result* res, int32_t detector, double* dst, int64_t max_hits);
 /* Kernel timing of the last trace: sum over step-kernel launches, HIP events on the trace stream. */
 int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* total_ms, int32_t* n_launches);
 /* Materialise host views (downloads + canonical ordering of the segment log). */

@@ -119,3 +119,29 @@ def test_acylinder_lenses(engine_ok, oracle):
     b = disc_bundle(2048, center=[0, -0.03, 0], direction=[0, 1, 0], diameter=22 * mm, e1=[1, 0, 0], jitter=5e-3)
     got, ref = run_both(oracle, bmo.System([a1, a2, det]), b, r_max=40)
     compare(got, ref, 0.0, "acyl")
+
+
+def test_split_form_and_host_hit_copy(engine_ok, oracle):
+    """bmo_batch_upload + bmo_trace_device + bmo_result_copy_hits into HOST memory + bmo_result_view give the same tables as
+    the one-call bmo_trace; a second view of a same-sized result (pinned tables reused from the pool) is identical too."""
+    system, _ = c2_scene()
+    bundle = c2_bundle(4096)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    ref = oracle.trace(scene, bundle, 100, threads=8)
+    eng = bmo.Engine(scene, 0)
+    try:
+        dev = eng.upload(bundle)
+        for rep in range(2):
+            res = eng.trace_device(dev, 100)
+            for slot in range(len(scene.detectors)):
+                _, cnt = eng.result_device_hits(res, slot)
+                assert cnt == int(ref.det_count[slot])
+                host = np.full((cnt + 1, 9), -7.0)
+                eng.result_copy_hits(res, slot, host.ctypes.data, cnt)
+                assert np.array_equal(host[:cnt], ref.detector_hits(slot)) and np.all(host[cnt] == -7.0)
+            got = eng.result_view(res)
+            eng.free_result(res)
+            compare(got, ref, 0.0, "split form rep %d" % rep)
+        eng.free_batch(dev)
+    finally:
+        eng.close()
