@@ -1,0 +1,155 @@
+"""Randomised parity: seeded random element trains (spherical / meniscus / doublet / aspheric / cylinder lenses, prisms, plate, cube and
+thin beam splitters, mirrors, detectors; random tilts and decentres) and random bundles of all three beam kinds.
+
+CPU: the engine's per-lane code (host emulator build of csrc/bmo_lane.hpp) must reproduce the oracle bit-exactly — this is what
+keeps the engine's result-preserving shortcuts (bounding-sphere culls, nearest-hit prune, union child skipping, hint reuse, start
+classification probe) honest on geometry nobody hand-picked.   GPU: the same scenes through the C ABI.
+Bar as everywhere: ids / counts / tree bit-exact, FP64 planes bit-exact for geometric rays, 1e-10 relative where libm enters.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bmo_amd as bmo
+from parity import compare, emu_trace
+from scenes import disc_bundle, gaussian_bundle, polarized_bundle
+
+mm = 1e-3
+D = 25.4 * mm
+R_MAX = 30
+
+
+def _radius(rng, allow_inf=True):
+    if allow_inf and rng.random() < 0.2:
+        return math.inf
+    return float(rng.choice([-1.0, 1.0]) * rng.uniform(25, 120) * mm)
+
+
+def _element(rng, allow_splitter):
+    """One random element centred near the origin with its optical axis along +y; returns (object, axial length, is_splitter)."""
+    kind = rng.choice(["singlet", "singlet", "doublet", "asphere", "cylinder", "plate_bs", "cube_bs", "thin_bs", "prism", "window"])
+    if kind.endswith("_bs") and not allow_splitter:
+        kind = "singlet"
+    obj, length = _make(rng, kind)
+    return obj, length, kind.endswith("_bs")
+
+
+def _make(rng, kind):
+    n = float(rng.uniform(1.4, 1.8))
+    if kind == "singlet":
+        r1, r2 = _radius(rng), _radius(rng)
+        if math.isinf(r1) and math.isinf(r2):
+            r2 = -60 * mm
+        l = float(rng.uniform(4, 8) * mm)
+        return bmo.Lens(bmo.SphericalSurface(r1, D), bmo.SphericalSurface(r2, D), l, lambda lam, n=n: n), l
+    if kind == "doublet":
+        r1, r2, r3 = float(rng.uniform(40, 90) * mm), -float(rng.uniform(30, 60) * mm), -float(rng.uniform(80, 200) * mm)
+        l1, l2 = float(rng.uniform(5, 8) * mm), float(rng.uniform(2, 3) * mm)
+        return bmo.SphericalDoubletLens(r1, r2, r3, l1, l2, D, n, float(rng.uniform(1.5, 1.8))), l1 + l2
+    if kind == "asphere":
+        l = float(rng.uniform(5, 7) * mm)
+        r = float(rng.uniform(25, 60) * mm)
+        front = bmo.EvenAsphericalSurface(r, D, float(rng.uniform(-1.2, 0.2)), [0.0, float(rng.uniform(-2, 2)), float(rng.uniform(-500, 500))])
+        back = bmo.SphericalSurface(_radius(rng), D)
+        return bmo.Lens(front, back, l, lambda lam, n=n: n), l
+    if kind == "cylinder":
+        l = float(rng.uniform(4, 6) * mm)
+        r = float(rng.choice([-1.0, 1.0]) * rng.uniform(30, 80) * mm)
+        return bmo.Lens(bmo.CylindricalSurface(r, 20 * mm, 22 * mm), l, lambda lam, n=n: n), l
+    if kind == "plate_bs":
+        o = bmo.RectangularPlateBeamsplitter(30 * mm, 30 * mm, 4 * mm, lambda lam, n=n: n, reflectance=float(rng.uniform(0.3, 0.7)))
+        bmo.xrotate3d(o, math.radians(float(rng.uniform(20, 45))))
+        return o, 25 * mm
+    if kind == "cube_bs":
+        o = bmo.CubeBeamsplitter(20 * mm, lambda lam, n=n: n)
+        bmo.zrotate3d(o, math.radians(float(rng.uniform(-4, 4))))
+        return o, 24 * mm
+    if kind == "thin_bs":
+        o = bmo.ThinBeamsplitter(30 * mm, reflectance=float(rng.uniform(0.3, 0.7)))
+        bmo.xrotate3d(o, math.radians(float(rng.uniform(30, 50))))
+        return o, 25 * mm
+    if kind == "prism":
+        o = bmo.RightAnglePrism(20 * mm, 25 * mm, lambda lam, n=n: n)
+        bmo.zrotate3d(o, math.radians(float(rng.uniform(0, 360))))
+        return o, 30 * mm
+    l = float(rng.uniform(1, 3) * mm)
+    return bmo.Lens(bmo.CircularFlatSurface(D), l, lambda lam, n=n: n), l
+
+
+def random_system(seed, with_detectors=True):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    objs = []
+    y = 0.0
+    n_bs = 0
+    for _ in range(int(rng.integers(3, 7))):
+        o, length, is_bs = _element(rng, n_bs == 0)  # one splitter per train: two facing each other multiply the beam tree without bound
+        n_bs += is_bs
+        bmo.xrotate3d(o, math.radians(float(rng.uniform(-4, 4))))
+        bmo.zrotate3d(o, math.radians(float(rng.uniform(-4, 4))))
+        bmo.translate3d(o, [float(rng.uniform(-1, 1) * mm), y, float(rng.uniform(-1, 1) * mm)])
+        objs.append(o)
+        y += length + float(rng.uniform(2, 15) * mm)
+    end = rng.choice(["mirror", "spot", "none"])
+    if end == "mirror":  # sends the bundle back through the train
+        m = bmo.RoundPlanoMirror(30 * mm, 5 * mm)
+        bmo.zrotate3d(m, math.radians(180 + float(rng.uniform(-2, 2))))
+        bmo.xrotate3d(m, math.radians(float(rng.uniform(-2, 2))))
+        bmo.translate3d(m, [0, y + 10 * mm, 0])
+        objs.append(m)
+    if with_detectors:
+        if end == "spot":
+            d = bmo.Spotdetector(40 * mm)
+            bmo.translate3d(d, [0, y + 10 * mm, 0])
+            objs.append(d)
+        side = bmo.Spotdetector(60 * mm)  # catches reflected arms of splitters
+        bmo.xrotate3d(side, math.radians(90))
+        bmo.translate3d(side, [0, y / 2, -60 * mm])
+        objs.append(side)
+    return bmo.System(objs), rng
+
+
+def random_bundle(rng, kind, n):
+    center = [float(rng.uniform(-1, 1) * mm), -20 * mm, float(rng.uniform(-1, 1) * mm)]
+    direction = [float(rng.uniform(-0.02, 0.02)), 1.0, float(rng.uniform(-0.02, 0.02))]
+    seed = int(rng.integers(1, 1 << 30))
+    lam = float(rng.choice([532e-9, 1064e-9]))
+    if kind == "ray":
+        return disc_bundle(n, center, direction, 0.7 * D, lam=lam, seed=seed, cone=float(rng.uniform(0.0, 0.06)))
+    if kind == "pol":
+        return polarized_bundle(n, center, direction, 0.6 * D, lam=lam, jitter=0.03, seed=seed)
+    return gaussian_bundle(n, center, direction, 0.4 * D, lam=lam, w0=float(rng.uniform(30e-6, 200e-6)), seed=seed)
+
+
+CASES = [(seed, "ray") for seed in range(101, 165)] + [(seed, "pol") for seed in range(201, 217)] + [(seed, "gauss") for seed in range(301, 317)]
+
+
+def _tol(kind):
+    return 0.0 if kind == "ray" else 1e-10
+
+
+def _case(seed, kind, n):
+    system, rng = random_system(seed, with_detectors=(kind != "gauss"))
+    bundle = random_bundle(rng, kind, n)
+    return bmo.CompiledScene(system, bundle.lambdas), bundle
+
+
+@pytest.mark.parametrize("seed,kind", CASES)
+def test_lane_code_equals_oracle_on_random_scenes(oracle, seed, kind):
+    scene, bundle = _case(seed, kind, 128 if kind == "ray" else 64)
+    ref = oracle.trace(scene, bundle, R_MAX, threads=4)
+    got = emu_trace(scene, bundle, R_MAX)
+    compare(got, ref, _tol(kind), "fuzz %d %s" % (seed, kind))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kind", CASES)
+def test_engine_equals_oracle_on_random_scenes(oracle, seed, kind):
+    scene, bundle = _case(seed, kind, 4096 if kind == "ray" else 1024)
+    ref = oracle.trace(scene, bundle, R_MAX, threads=16)
+    eng = bmo.Engine(scene, 0)
+    try:
+        got = eng.trace(bundle, R_MAX)
+    finally:
+        eng.close()
+    compare(got, ref, _tol(kind), "fuzz gpu %d %s" % (seed, kind))
