@@ -140,7 +140,7 @@ struct NodeArrays {
     int32_t* status;
     int32_t* li;
     int32_t* hit_det;
-    unsigned long long* key;  // root<<32 | depth<<26 | path
+    unsigned long long* key;  // depth<<32 | path: one bit per tree level, newest lowest (0 transmitted, 1 reflected), last 32 levels kept
     double* lambda;
     double* hit;  // [cap][9 * hit_sub]
     double* aux;  // [cap][4]: Gaussian l0 (length of parent chief), w0, Re(E0), Im(E0)
@@ -473,18 +473,19 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             const int64_t cn = (int64_t)al.node_base + 2 * r;
             if (cn + 1 < P.nodes.cap) {
                 const unsigned long long pkey = P.nodes.key[node];
-                const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+                const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
+                const int32_t root = P.nodes.root[node];
                 atomicMax(&P.ctr->max_depth, depth + 1ull);
                 for (int w = 0; w < 2; ++w) {
                     const int64_t c = cn + w;
-                    P.nodes.root[c] = (int32_t)root;
+                    P.nodes.root[c] = root;
                     P.nodes.parent[c] = node;
                     P.nodes.nseg[c] = 1;
                     P.nodes.status[c] = 0;
                     P.nodes.li[c] = li;
                     P.nodes.lambda[c] = lambda;
                     P.nodes.hit_det[c] = -1;
-                    P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                    P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
                     if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
                 }
                 const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
@@ -634,18 +635,19 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
         const int64_t cn = (int64_t)al.node_base + 2 * r;
         if (cn + 1 < P.nodes.cap) {
             const unsigned long long pkey = P.nodes.key[node];
-            const unsigned long long root = pkey >> 32, depth = (pkey >> 26) & 63ull, path = pkey & ((1ull << 26) - 1ull);
+            const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
+            const int32_t root = P.nodes.root[node];
             atomicMax(&P.ctr->max_depth, depth + 1ull);
             for (int w = 0; w < 2; ++w) {
                 const int64_t c = cn + w;
-                P.nodes.root[c] = (int32_t)root;
+                P.nodes.root[c] = root;
                 P.nodes.parent[c] = node;
                 P.nodes.nseg[c] = 1;
                 P.nodes.status[c] = 0;
                 P.nodes.li[c] = g.li;
                 P.nodes.lambda[c] = g.lambda;
                 P.nodes.hit_det[c] = -1;
-                P.nodes.key[c] = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
                 P.nodes.aux[c * 4 + 0] = o.child_l0;
                 P.nodes.aux[c * 4 + 1] = o.child_w0;
                 P.nodes.aux[c * 4 + 2] = w == 0 ? o.Et.re : o.Er.re;
@@ -705,7 +707,7 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
     nodes.li[j] = lambda_idx[j];
     nodes.lambda[j] = lam;
     nodes.hit_det[j] = -1;
-    nodes.key[j] = ((unsigned long long)j) << 32;
+    nodes.key[j] = 0;
 }
 
 // retrace tables of a finished solution
@@ -723,16 +725,61 @@ __global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const
     if (p >= 0 && !(key[c] & 1ull)) first_child[p] = (int32_t)c;  // transmitted child (path bit 0); the reflected one is c + 1
 }
 // (root, depth, path) keys packed into as few bits as this solve needs: the radix sort of the final ordering runs 3-4 passes over
-// 32-bit keys instead of 8 over 64-bit ones
-__global__ void pack_keys_kernel(const unsigned long long* __restrict__ key, int64_t n, int bits_depth, int bits_path, uint32_t* __restrict__ k32,
-                                 unsigned long long* __restrict__ k64) {
+// 32-bit keys instead of 8 over 64-bit ones.  Trees of up to MAX_PATH_LEVELS levels.
+constexpr int MAX_PATH_LEVELS = 26;
+__global__ void pack_keys_kernel(const int32_t* __restrict__ root_of, const unsigned long long* __restrict__ key, int64_t n, int bits_depth, int bits_path,
+                                 uint32_t* __restrict__ k32, unsigned long long* __restrict__ k64) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = key[i];
-    const unsigned long long root = k >> 32, depth = (k >> 26) & 63ull, path = k & ((1ull << 26) - 1ull);
+    const unsigned long long root = (unsigned long long)root_of[i], depth = k >> 32, path = k & ((1ull << bits_path) - 1ull);
     const unsigned long long packed = (root << (bits_depth + bits_path)) | (depth << bits_path) | path;
     if (k32) k32[i] = (uint32_t)packed;
     else k64[i] = packed;
+}
+// ---- ordering of beam trees deeper than MAX_PATH_LEVELS (cavities: a splitter facing a mirror): the path no longer fits a key, so
+// the rank of every node within its tree level is built level by level from its parent's rank (a splitting beam has exactly two
+// children, transmitted first): rank(child) = 2 * #(splitting parents of smaller rank) + w.
+__global__ void node_depth_kernel(const unsigned long long* __restrict__ key, int64_t n, uint32_t* __restrict__ depth) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) depth[i] = (uint32_t)(key[i] >> 32);
+}
+__global__ void level_starts_kernel(const uint32_t* __restrict__ sorted_depth, int64_t n, int64_t max_depth, int32_t* __restrict__ start) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t d = sorted_depth[i], dprev = i ? (int64_t)sorted_depth[i - 1] : -1;
+    for (int64_t x = dprev + 1; x <= d; ++x) start[x] = (int32_t)i;
+    if (i == n - 1)
+        for (int64_t x = d + 1; x <= max_depth + 1; ++x) start[x] = (int32_t)n;
+}
+__global__ void level_root_rank_kernel(const int32_t* __restrict__ ids, int32_t cnt, int32_t* __restrict__ rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) rank[ids[i]] = i;  // level 0: the roots, in node id = bundle order (the depth sort is stable)
+}
+__global__ void level_flag_kernel(const int32_t* __restrict__ ids, int32_t cnt, const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key,
+                                  const int32_t* __restrict__ rank, int32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int32_t nd = ids[i];
+    if (!(key[nd] & 1ull)) flag[rank[parent[nd]]] = 1;
+}
+__global__ void level_rank_kernel(const int32_t* __restrict__ ids, int32_t cnt, const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key,
+                                  const int32_t* __restrict__ scan, int32_t* __restrict__ rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int32_t nd = ids[i];
+    rank[nd] = 2 * scan[rank[parent[nd]]] + (int32_t)(key[nd] & 1ull);
+}
+__global__ void gather_u32_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ src, int64_t n, uint32_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (uint32_t)src[idx[i]];
+}
+__global__ void root_depth_key_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ root_of, const unsigned long long* __restrict__ key, int64_t n,
+                                      int bits_depth, unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t nd = idx[i];
+    out[i] = ((unsigned long long)root_of[nd] << bits_depth) | (key[nd] >> 32);
 }
 __global__ void iota_kernel(int32_t* a, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1333,29 +1380,86 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             while (b < 64 && (v >> b)) ++b;
             return b;
         };
-        const int max_depth = (int)std::min<unsigned long long>(h_ctr.max_depth, 26);  // path has one bit per level (26 kept)
-        const int bits_path = max_depth, bits_depth = bits_for(h_ctr.max_depth), bits_root = bits_for((unsigned long long)std::max<int64_t>(n - 1, 0));
-        const int bits = bits_root + bits_depth + bits_path;
-        const bool narrow = bits <= 32;
+        const int bits_depth = bits_for(h_ctr.max_depth), bits_root = bits_for((unsigned long long)std::max<int64_t>(n - 1, 0));
         DevBuf keys_in, keys_out, vals_out, tmp;
-        if ((rc = keys_in.alloc((size_t)n_nodes * (narrow ? 4 : 8))) || (rc = keys_out.alloc((size_t)n_nodes * (narrow ? 4 : 8))) ||
-            (rc = vals_out.alloc((size_t)n_nodes * 4)))
-            return rc;
-        hipLaunchKernelGGL(pack_keys_kernel, dim3(nb), dim3(256), 0, stream, (const unsigned long long*)R->n_key.p, n_nodes, bits_depth, bits_path,
-                           narrow ? (uint32_t*)keys_in.p : nullptr, narrow ? nullptr : (unsigned long long*)keys_in.p);
-        size_t tmp_bytes = 0;
-        if (narrow) {
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
-                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
-            if ((rc = tmp.alloc(tmp_bytes))) return rc;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
-                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+        static const bool force_deep = std::getenv("BMO_FORCE_DEEP_ORDER") != nullptr;  // test hook: take the deep-tree path for any tree
+        if (h_ctr.max_depth <= (unsigned long long)MAX_PATH_LEVELS && !force_deep) {
+            const int bits_path = (int)h_ctr.max_depth;  // one bit per level
+            const int bits = bits_root + bits_depth + bits_path;
+            const bool narrow = bits <= 32;
+            if ((rc = keys_in.alloc((size_t)n_nodes * (narrow ? 4 : 8))) || (rc = keys_out.alloc((size_t)n_nodes * (narrow ? 4 : 8))) ||
+                (rc = vals_out.alloc((size_t)n_nodes * 4)))
+                return rc;
+            hipLaunchKernelGGL(pack_keys_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes, bits_depth,
+                               bits_path, narrow ? (uint32_t*)keys_in.p : nullptr, narrow ? nullptr : (unsigned long long*)keys_in.p);
+            size_t tmp_bytes = 0;
+            if (narrow) {
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
+                                                           (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+                if ((rc = tmp.alloc(tmp_bytes))) return rc;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
+                                                           (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+            } else {
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
+                                                           (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+                if ((rc = tmp.alloc(tmp_bytes))) return rc;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
+                                                           (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+            }
         } else {
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
-                                                       (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
-            if ((rc = tmp.alloc(tmp_bytes))) return rc;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
-                                                       (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+            // deep trees: ranks within each tree level, level by level, then sort by (root, depth, rank)
+            const int64_t md = (int64_t)h_ctr.max_depth;
+            const int32_t* parent = (const int32_t*)R->n_parent.p;
+            const unsigned long long* key = (const unsigned long long*)R->n_key.p;
+            DevBuf depth, depth_sorted, by_depth, starts, rank, flag, scan, k64, k64_out, ids2;
+            if ((rc = depth.alloc((size_t)n_nodes * 4)) || (rc = depth_sorted.alloc((size_t)n_nodes * 4)) || (rc = by_depth.alloc((size_t)n_nodes * 4)) ||
+                (rc = starts.alloc((size_t)(md + 2) * 4)) || (rc = rank.alloc((size_t)n_nodes * 4)) || (rc = flag.alloc((size_t)n_nodes * 4)) ||
+                (rc = scan.alloc((size_t)n_nodes * 4)) || (rc = k64.alloc((size_t)n_nodes * 8)) || (rc = k64_out.alloc((size_t)n_nodes * 8)) ||
+                (rc = ids2.alloc((size_t)n_nodes * 4)) || (rc = vals_out.alloc((size_t)n_nodes * 4)) || (rc = keys_in.alloc((size_t)n_nodes * 4)) ||
+                (rc = keys_out.alloc((size_t)n_nodes * 4)))
+                return rc;
+            hipLaunchKernelGGL(node_depth_kernel, dim3(nb), dim3(256), 0, stream, key, n_nodes, (uint32_t*)depth.p);
+            size_t tb = 0, tb2 = 0, tb3 = 0, tb4 = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)depth.p, (uint32_t*)depth_sorted.p, (const int32_t*)R->order.p,
+                                                       (int32_t*)by_depth.p, (int)n_nodes, 0, bits_depth, stream));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (const int32_t*)flag.p, (int32_t*)scan.p, (int)n_nodes, stream));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
+                                                       (int32_t*)ids2.p, (int)n_nodes, 0, 32, stream));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, (const unsigned long long*)k64.p, (unsigned long long*)k64_out.p, (const int32_t*)ids2.p,
+                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, 64, stream));
+            if ((rc = tmp.alloc(std::max(std::max(tb, tb2), std::max(tb3, tb4))))) return rc;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, (const uint32_t*)depth.p, (uint32_t*)depth_sorted.p, (const int32_t*)R->order.p,
+                                                       (int32_t*)by_depth.p, (int)n_nodes, 0, bits_depth, stream));
+            hipLaunchKernelGGL(level_starts_kernel, dim3(nb), dim3(256), 0, stream, (const uint32_t*)depth_sorted.p, n_nodes, md, (int32_t*)starts.p);
+            std::vector<int32_t> h_start((size_t)md + 2);
+            HIP_TRY(hipMemcpyAsync(h_start.data(), starts.p, (size_t)(md + 2) * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            const int32_t* ids = (const int32_t*)by_depth.p;
+            hipLaunchKernelGGL(level_root_rank_kernel, dim3((unsigned)((h_start[1] + 255) / 256)), dim3(256), 0, stream, ids, h_start[1], (int32_t*)rank.p);
+            int32_t max_level = h_start[1];
+            for (int64_t d = 1; d <= md; ++d) {
+                const int32_t cnt_prev = h_start[d] - h_start[d - 1], cnt = h_start[d + 1] - h_start[d];
+                if (cnt <= 0 || cnt_prev <= 0) continue;
+                max_level = std::max(max_level, cnt);
+                const unsigned lb = (unsigned)((cnt + 255) / 256);
+                HIP_TRY(hipMemsetAsync(flag.p, 0, (size_t)cnt_prev * 4, stream));
+                hipLaunchKernelGGL(level_flag_kernel, dim3(lb), dim3(256), 0, stream, ids + h_start[d], cnt, parent, key, (const int32_t*)rank.p, (int32_t*)flag.p);
+                size_t t = tmp.bytes;
+                HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, (const int32_t*)flag.p, (int32_t*)scan.p, (int)cnt_prev, stream));
+                hipLaunchKernelGGL(level_rank_kernel, dim3(lb), dim3(256), 0, stream, ids + h_start[d], cnt, parent, key, (const int32_t*)scan.p, (int32_t*)rank.p);
+            }
+            // LSD: by rank within the level, then (stable) by (root, depth)
+            hipLaunchKernelGGL(gather_u32_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)rank.p, n_nodes, (uint32_t*)keys_in.p);
+            size_t t3 = tmp.bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t3, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p, (int32_t*)ids2.p,
+                                                       (int)n_nodes, 0, bits_for((unsigned long long)max_level), stream));
+            hipLaunchKernelGGL(root_depth_key_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)ids2.p, (const int32_t*)R->n_root.p, key, n_nodes, bits_depth,
+                               (unsigned long long*)k64.p);
+            size_t t4 = tmp.bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t4, (const unsigned long long*)k64.p, (unsigned long long*)k64_out.p, (const int32_t*)ids2.p,
+                                                       (int32_t*)vals_out.p, (int)n_nodes, 0, bits_root + bits_depth, stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));  // the level tables go back to the pool
         }
         HIP_TRY(hipStreamSynchronize(stream));
         std::swap(R->order.p, vals_out.p);

@@ -26,6 +26,29 @@ struct NodeE {
     double lambda, hit[9];
     int old = -1;  // node of the previous solution this beam re-walks (retrace), -1 = fresh
 };
+// reference order of the beam nodes: bundle order x breadth-first order of each root's tree (the two children of a splitting beam are
+// created consecutively, transmitted first).  Any tree depth.
+template <class N>
+void bfs_order(const std::vector<N>& nodes, int64_t n_roots, std::vector<int>& order) {
+    const int64_t nn = (int64_t)nodes.size();
+    std::vector<int> first_kid(nn, -1);
+    for (int64_t c = 0; c < nn; ++c)
+        if (nodes[c].parent >= 0 && first_kid[nodes[c].parent] < 0) first_kid[nodes[c].parent] = (int)c;
+    order.clear();
+    order.reserve(nn);
+    for (int64_t r = 0; r < n_roots; ++r) {
+        size_t head = order.size();
+        order.push_back((int)r);
+        while (head < order.size()) {
+            const int k = first_kid[order[head++]];
+            if (k >= 0) {
+                order.push_back(k);
+                order.push_back(k + 1);
+            }
+        }
+    }
+}
+
 // node index of every root beam in a canonical result view (roots are the nodes without parent, in bundle order)
 std::vector<int> old_roots(const bmo_trace_result_view* prev) {
     std::vector<int> r;
@@ -76,7 +99,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
         r.hobj = r.hshape = -1;
         r.flags = (1 < opts->r_max) ? 0 : 1;
         r.opl = 0;
-        nodes[j] = NodeE{(int)j, -1, 1, 0, in->lambda_idx[j], -1, ((unsigned long long)j) << 32, P[6 * n + j], {0}};
+        nodes[j] = NodeE{(int)j, -1, 1, 0, in->lambda_idx[j], -1, 0ull, P[6 * n + j], {0}};
         if (prev) {
             nodes[j].old = oroot[j];
             r.flags = 0;  // the retrace walk ignores r_max (System.jl:197)
@@ -170,10 +193,9 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                 nodes[r.node].old = -1;
             }
             if (o.outcome == OUT_SPLIT && !(r.flags & 1) && X.shape >= 0) {
-                unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
+                const int root = nodes[r.node].root;
                 for (int w = 0; w < 2; ++w) {
-                    NodeE c2{(int)root, r.node, 1, 0, nd.li, -1, (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull)),
-                             nd.lambda, {0}};
+                    NodeE c2{root, r.node, 1, 0, nd.li, -1, (unsigned long long)w, nd.lambda, {0}};
                     if (old_kids) c2.old = prev->node_first_child[old] + w;  // children!: _modify_beam_head! of the stored child
                     nodes.push_back(c2);
                     Rec q;
@@ -199,8 +221,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     // canonical order
     const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
     std::vector<int> order(nn), rank(nn);
-    for (int64_t i = 0; i < nn; ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].key < nodes[b].key; });
+    bfs_order(nodes, n, order);
     for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int)i;
     const int PL = KIND == BMO_BEAM_RAY ? 11 : 17;
     R.root.resize(nn);
@@ -338,7 +359,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
         nd.nseg = 1;
         nd.li = r.g.li;
         nd.hit_det = -1;
-        nd.key = ((unsigned long long)j) << 32;
+        nd.key = 0;
         nd.lambda = r.g.lambda;
         nd.w0 = r.g.w0;
         nd.E0 = r.g.E0;
@@ -422,15 +443,15 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                                     (keep_walking || r.k + 2 < opts->r_max) ? 0 : 1, r.o.lenA, r.o.lenB, r.o.oplC, r.o.oplW, r.o.oplD, nodes[r.node]));
             }
             if (!(r.flags & 1) && r.o.outcome == OUT_SPLIT) {
-                unsigned long long pk = nodes[r.node].key, root = pk >> 32, depth = (pk >> 26) & 63ull, path = pk & ((1ull << 26) - 1ull);
+                const int root = nodes[r.node].root;
                 for (int w = 0; w < 2; ++w) {
                     GNode c2{};
-                    c2.root = (int)root;
+                    c2.root = root;
                     c2.parent = r.node;
                     c2.nseg = 1;
                     c2.li = r.g.li;
                     c2.hit_det = -1;
-                    c2.key = (root << 32) | ((depth + 1) << 26) | (((path << 1) | (unsigned long long)w) & ((1ull << 26) - 1ull));
+                    c2.key = (unsigned long long)w;
                     c2.lambda = r.g.lambda;
                     c2.l0 = r.o.child_l0;
                     c2.w0 = r.o.child_w0;
@@ -453,8 +474,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
     }
     const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
     std::vector<int> order(nn), rank(nn);
-    for (int64_t i = 0; i < nn; ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].key < nodes[b].key; });
+    bfs_order(nodes, n, order);
     for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int)i;
     const int PL = 33;
     R.root.resize(nn);

@@ -153,3 +153,32 @@ def test_engine_equals_oracle_on_random_scenes(oracle, seed, kind):
     finally:
         eng.close()
     compare(got, ref, _tol(kind), "fuzz gpu %d %s" % (seed, kind))
+
+
+# A cube splitter facing a mirror: one root's beam tree is more than 64 levels deep although it has only ~1.5k beams.  The node
+# order (bundle order x breadth-first per tree) must hold for any depth (found by the random sweep, seed 1008).
+DEEP_SEED = 1008
+
+
+def test_deep_beam_tree_lane_code(oracle):
+    scene, bundle = _case(DEEP_SEED, "ray", 128)
+    ref = oracle.trace(scene, bundle, R_MAX, threads=4)
+    depth = np.zeros(ref.n_nodes, dtype=np.int64)
+    for i in range(ref.n_nodes):  # canonical order: parents come before children
+        if ref.node_parent[i] >= 0:
+            depth[i] = depth[ref.node_parent[i]] + 1
+    assert depth.max() > 64
+    compare(emu_trace(scene, bundle, R_MAX), ref, 0.0, "deep tree")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ray", "gauss"])
+def test_deep_beam_tree_engine(oracle, kind):
+    scene, bundle = _case(DEEP_SEED, kind, 128)
+    ref = oracle.trace(scene, bundle, R_MAX, threads=16)
+    eng = bmo.Engine(scene, 0)
+    try:
+        got = eng.trace(bundle, R_MAX)
+    finally:
+        eng.close()
+    compare(got, ref, _tol(kind), "deep tree gpu " + kind)
