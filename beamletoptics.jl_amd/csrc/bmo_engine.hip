@@ -1473,6 +1473,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (nd > 0 && n_nodes > 0) {
         DevBuf flags, offs, tmp;
         const int64_t tot = (int64_t)nd * n_nodes;
+        if (tot >= ((int64_t)1 << 31)) return fail(BMO_ERR_UNSUPPORTED, "detectors x beams exceeds 2^31: split the batch");
         if ((rc = flags.alloc((size_t)tot * 4)) || (rc = offs.alloc((size_t)tot * 4))) return rc;
         hipLaunchKernelGGL(hit_flags_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p, n_nodes, nd,
                            nsub, (int32_t*)flags.p);
@@ -1751,6 +1752,7 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
     HIP_TRY(hipSetDevice(r->device));
     if (!r->viewed) {
         const int64_t nn = r->n_nodes, nr = r->n_records;
+        if (nr >= ((int64_t)1 << 31)) return fail(BMO_ERR_UNSUPPORTED, "result view: more than 2^31 segments (node_first_rec is 32-bit)");
         std::vector<int32_t> root, parent, nseg, status, order;
         std::vector<double> lambda;
         int rc;
