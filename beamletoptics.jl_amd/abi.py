@@ -52,7 +52,7 @@ class RayBatch(C.Structure):
 
 
 class TraceOpts(C.Structure):
-    _fields_ = [("r_max", C.c_int32), ("device", C.c_int32), ("record_segments", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("r_max", C.c_int32), ("device", C.c_int32), ("record_segments", C.c_int32), ("max_beams", C.c_int32)]
 
 
 class ResultView(C.Structure):

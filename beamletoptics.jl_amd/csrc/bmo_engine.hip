@@ -1335,6 +1335,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         shrink_last(nxt, (int64_t)produced);
         keep_ratio = (double)std::min<unsigned long long>(produced, (unsigned long long)m) / (double)m;
         n_nodes = (int64_t)h_ctr.node_count;
+        if (opts->max_beams > 0 && n_nodes > (int64_t)opts->max_beams)
+            return fail(BMO_ERR_LIMIT, "beam tree exceeds bmo_trace_opts.max_beams (" + std::to_string(n_nodes) + " beams after " + std::to_string(steps) +
+                                           " launches): a splitter facing a mirror?");
         cur = nxt;
     }
     for (int q = 0; q < steps; ++q) {

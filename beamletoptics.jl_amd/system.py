@@ -185,10 +185,11 @@ def make_batch(scene, bundle):
 class Engine:
     """Thin RAII wrapper over the C ABI for one compiled scene."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, max_beams=0):
         self.lib = abi.load_engine()
         self.scene = scene
         self.device = device
+        self.max_beams = max_beams  # bmo_trace_opts.max_beams: 0 = no limit (reference behaviour)
         self.handle = C.c_void_p()
         abi.check(self.lib, self.lib.bmo_scene_create(C.byref(scene.desc), C.byref(self.handle)), "bmo_scene_create")
 
@@ -205,7 +206,7 @@ class Engine:
 
     def opts(self, r_max, record_segments=True):
         o = abi.TraceOpts()
-        o.r_max, o.device, o.record_segments, o.reserved = int(r_max), int(self.device), int(bool(record_segments)), 0
+        o.r_max, o.device, o.record_segments, o.max_beams = int(r_max), int(self.device), int(bool(record_segments)), int(self.max_beams)
         return o
 
     def trace(self, bundle, r_max=100):

@@ -47,7 +47,8 @@ enum bmo_status {
     BMO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure           */
     BMO_ERR_OOM = -3,         /* device or host allocation failed              */
     BMO_ERR_UNSUPPORTED = -4, /* shape/object/beam kind not built yet          */
-    BMO_ERR_INTERNAL = -5
+    BMO_ERR_INTERNAL = -5,
+    BMO_ERR_LIMIT = -6        /* bmo_trace_opts.max_beams exceeded             */
 };
 
 /* per-node status bits (node_status) */
@@ -211,7 +212,10 @@ typedef struct bmo_trace_opts {
     int32_t r_max;              /* solve_system! default 100 (System.jl:444)         */
     int32_t device;             /* HIP device ordinal                                */
     int32_t record_segments;    /* 1: keep the full segment log (reference behaviour) */
-    int32_t reserved;
+    int32_t max_beams;          /* 0: no limit (reference behaviour).  > 0: stop with BMO_ERR_LIMIT once the solve holds more
+                                   than this many beams (tree nodes).  A splitter facing a mirror multiplies beams on every
+                                   pass; solve_system! recurses until memory runs out on such a system, and so does this
+                                   library (BMO_ERR_OOM after filling HBM) unless a limit is set.                      */
 } bmo_trace_opts;
 
 /* ------------------------------------------------------------------ result

@@ -27,7 +27,7 @@ def emu_trace(scene, bundle, r_max=100, prev=None):
                                          C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
     batch, keep = bmo.make_batch(scene, bundle)
     o = abi.TraceOpts()
-    o.r_max, o.device, o.record_segments, o.reserved = int(r_max), 0, 1, 0
+    o.r_max, o.device, o.record_segments, o.max_beams = int(r_max), 0, 1, 0
     h = C.c_void_p()
     v = abi.ResultView()
     if prev is None:

@@ -145,3 +145,20 @@ def test_split_form_and_host_hit_copy(engine_ok, oracle):
         eng.free_batch(dev)
     finally:
         eng.close()
+
+
+def test_max_beams_limit(engine_ok):
+    """bmo_trace_opts.max_beams stops a solve whose beam tree outgrows the limit with BMO_ERR_LIMIT; 0 / a generous limit do not."""
+    system, _ = c2_scene()
+    bundle = c2_bundle(1024)  # one splitter: 3 beams per ray
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    for limit, ok in ((0, True), (3 * 1024, True), (2000, False)):
+        eng = bmo.Engine(scene, 0, max_beams=limit)
+        try:
+            if ok:
+                assert eng.trace(bundle, 100).n_nodes == 3 * 1024
+            else:
+                with pytest.raises(RuntimeError, match=r"\(-6\).*max_beams"):
+                    eng.trace(bundle, 100)
+        finally:
+            eng.close()
