@@ -1881,7 +1881,9 @@ int bmo_cpu_photodetector_field(void* handle, int detector, const double* positi
             queue.pop_front();
             for (const auto& ch : g->children) queue.push_back(ch.get());
             const Ray& ray = g->chief.rays.back();
-            if (!ray.has_isect) continue;
+            // only beamlets the detector's interact3d ran for: a beamlet whose chief ray reaches the detector while its waist or
+            // divergence ray misses it ends in trace_system! (System.jl:283-296) before any interaction
+            if (!ray.has_isect || !(g->status & BMO_NODE_DETECTED)) continue;
             const bmo_object& o = R->objects[(size_t)ray.isect.obj];
             if (o.kind != BMO_OBJ_PHOTODETECTOR || o.detector != detector) continue;
             const double len_g = len_beam(g->chief);

@@ -105,6 +105,12 @@ def random_system(seed, with_detectors=True):
         bmo.xrotate3d(m, math.radians(float(rng.uniform(-2, 2))))
         bmo.translate3d(m, [0, y + 10 * mm, 0])
         objs.append(m)
+    if not with_detectors and end != "mirror":  # Gaussian bundles: a tilted Photodetector behind the train (f2)
+        pd = bmo.Photodetector(30 * mm, 24)
+        bmo.xrotate3d(pd, math.radians(float(rng.uniform(-5, 5))))
+        bmo.zrotate3d(pd, math.radians(float(rng.uniform(-5, 5))))
+        bmo.translate3d(pd, [0, y + 10 * mm, 0])
+        objs.append(pd)
     if with_detectors:
         if end == "spot":
             d = bmo.Spotdetector(40 * mm)
@@ -239,3 +245,28 @@ def test_engine_retrace_equals_oracle_on_random_moves(oracle, seed, kind):
     compare(g1, a1, _tol(kind), "retrace fuzz gpu %d %s retrace" % (seed, kind))
     h0.free()
     h1.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------- Photodetector read-out
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(301, 317))
+def test_engine_photodetector_field_on_random_scenes(oracle, seed):
+    """Random Gaussian bundles through random trains onto a tilted Photodetector: recorded beamlets and the accumulated complex
+    field (bmo_photodetector_field) against the oracle."""
+    scene, bundle = _case(seed, "gauss", 512)
+    if not scene.detectors:
+        pytest.skip("train ends in a mirror: no detector in this draw")
+    a, osol = oracle.trace(scene, bundle, R_MAX, threads=16, keep=True)
+    g, gsol = bmo.system._engine_solve(scene, bundle, R_MAX, None)
+    compare(g, a, 1e-10, "pd fuzz %d" % seed)
+    pd = scene.detectors[0]
+    fa = np.zeros((len(pd.x), len(pd.y)), dtype=np.complex128)
+    fg = fa.copy()
+    osol.photodetector_field(0, pd.position(), pd.orientation(), pd.x, pd.y, fa)
+    gsol.photodetector_field(0, pd.position(), pd.orientation(), pd.x, pd.y, fg)
+    peak = np.abs(fa).max()
+    if int(a.det_count[0]) > 0:
+        assert peak > 0
+    assert np.abs(fg - fa).max() <= 1e-9 * max(peak, 1e-300)
+    gsol.free()
+    osol.free()
