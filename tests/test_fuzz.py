@@ -98,7 +98,7 @@ def random_system(seed, with_detectors=True):
         bmo.translate3d(o, [float(rng.uniform(-1, 1) * mm), y, float(rng.uniform(-1, 1) * mm)])
         objs.append(o)
         y += length + float(rng.uniform(2, 15) * mm)
-    end = rng.choice(["mirror", "spot", "none"])
+    end = rng.choice(["mirror", "spot", "psf", "none"])
     if end == "mirror":  # sends the bundle back through the train
         m = bmo.RoundPlanoMirror(30 * mm, 5 * mm)
         bmo.zrotate3d(m, math.radians(180 + float(rng.uniform(-2, 2))))
@@ -112,8 +112,9 @@ def random_system(seed, with_detectors=True):
         bmo.translate3d(pd, [0, y + 10 * mm, 0])
         objs.append(pd)
     if with_detectors:
-        if end == "spot":
-            d = bmo.Spotdetector(40 * mm)
+        if end in ("spot", "psf"):
+            d = bmo.Spotdetector(40 * mm) if end == "spot" else bmo.PSFDetector(40 * mm)
+            bmo.xrotate3d(d, math.radians(float(rng.uniform(-5, 5))))
             bmo.translate3d(d, [0, y + 10 * mm, 0])
             objs.append(d)
         side = bmo.Spotdetector(60 * mm)  # catches reflected arms of splitters
@@ -169,27 +170,46 @@ def test_engine_equals_oracle_on_random_scenes(oracle, seed, kind):
     compare(got, ref, _tol(kind), "fuzz gpu %d %s" % (seed, kind))
 
 
-# A cube splitter facing a mirror: one root's beam tree is more than 64 levels deep although it has only ~1.5k beams.  The node
-# order (bundle order x breadth-first per tree) must hold for any depth (found by the random sweep, seed 1008).
-DEEP_SEED = 1008
+# A cube splitter between two mirrors, one tilted by 0.003 deg: every pass through the cube sheds one beam sideways and the cavity beam
+# walks off only after ~90 passes, so each root's beam tree is ~87 levels deep although it has only ~170 beams.  The node order
+# (bundle order x breadth-first per tree) must hold for any depth (a random sweep found the engine's old 26 / 64-level key limits).
+def cavity_case(kind, n):
+    a = bmo.RoundPlanoMirror(30 * mm, 5 * mm)
+    bmo.translate3d(a, [0, -30 * mm, 0])
+    cube = bmo.CubeBeamsplitter(20 * mm, lambda lam: 1.5)
+    b = bmo.RoundPlanoMirror(30 * mm, 5 * mm)
+    bmo.zrotate3d(b, math.radians(180))
+    bmo.xrotate3d(b, math.radians(0.003))
+    bmo.translate3d(b, [0, 40 * mm, 0])
+    system = bmo.System([a, cube, b])
+    if kind == "ray":
+        bundle = disc_bundle(n, [0, -20 * mm, 0], [0, 1, 0], 2 * mm, jitter=1e-4)
+    else:
+        bundle = gaussian_bundle(n, [0, -20 * mm, 0], [0, 1, 0], 2 * mm, w0=200e-6, jitter=1e-4)
+    return bmo.CompiledScene(system, bundle.lambdas), bundle
+
+
+def _tree_depth(res):
+    depth = np.zeros(res.n_nodes, dtype=np.int64)
+    for i in range(res.n_nodes):  # canonical order: parents come before children
+        if res.node_parent[i] >= 0:
+            depth[i] = depth[res.node_parent[i]] + 1
+    return int(depth.max())
 
 
 def test_deep_beam_tree_lane_code(oracle):
-    scene, bundle = _case(DEEP_SEED, "ray", 128)
+    scene, bundle = cavity_case("ray", 8)
     ref = oracle.trace(scene, bundle, R_MAX, threads=4)
-    depth = np.zeros(ref.n_nodes, dtype=np.int64)
-    for i in range(ref.n_nodes):  # canonical order: parents come before children
-        if ref.node_parent[i] >= 0:
-            depth[i] = depth[ref.node_parent[i]] + 1
-    assert depth.max() > 64
+    assert _tree_depth(ref) > 64
     compare(emu_trace(scene, bundle, R_MAX), ref, 0.0, "deep tree")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["ray", "gauss"])
 def test_deep_beam_tree_engine(oracle, kind):
-    scene, bundle = _case(DEEP_SEED, kind, 128)
+    scene, bundle = cavity_case(kind, 300)
     ref = oracle.trace(scene, bundle, R_MAX, threads=16)
+    assert _tree_depth(ref) > 64
     eng = bmo.Engine(scene, 0)
     try:
         got = eng.trace(bundle, R_MAX)
