@@ -379,9 +379,9 @@ class EngineSolution:
         return ms.value
 
 
-def _engine_solve(scene, bundle, r_max, prev, device=0):
+def _engine_solve(scene, bundle, r_max, prev, device=0, max_beams=0):
     """One solve on the HIP engine: bmo_trace, or bmo_retrace when `prev` (an EngineSolution) is given."""
-    eng = Engine(scene, device)
+    eng = Engine(scene, device, max_beams)
     try:
         batch, keep = make_batch(scene, bundle)
         h = C.c_void_p()
