@@ -161,6 +161,7 @@ def load_engine():
     lib.bmo_result_device_hits.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64)]
     lib.bmo_result_copy_hits.argtypes = [vp, C.c_int32, C.c_void_p, C.c_int64]
     lib.bmo_result_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.bmo_result_counts.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.bmo_result_view.argtypes = [vp, C.POINTER(ResultView)]
     lib.bmo_result_free.argtypes = [vp]
     lib.bmo_retrace.argtypes = [vp, C.POINTER(RayBatch), vp, C.POINTER(TraceOpts), C.POINTER(vp)]

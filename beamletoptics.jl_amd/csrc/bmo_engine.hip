@@ -159,13 +159,14 @@ struct OldSolution {
     const double* aux;           // Gaussian: [node][4] = l0, w0, Re E0, Im E0
 };
 
+constexpr int MAX_FUSE = 8;
 struct StepParams {
     const char* blob;
     uint32_t blob_bytes;
     int32_t use_lds;
     Chunk cur, nxt;
-    Chunk inner[3];   // in-place levels 1..n_fuse-1 of this launch (Beam kernels; capacity >= cur.count, same slot numbering as cur)
-    int32_t n_fuse;   // bounces per launch, 1..4
+    Chunk inner[MAX_FUSE - 1];   // in-place levels 1..n_fuse-1 of this launch (Beam kernels; capacity >= cur.count, same slot numbering as cur)
+    int32_t n_fuse;   // bounces per launch, 1..MAX_FUSE
     Counters* ctr;
     unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
     NodeArrays nodes;
@@ -1284,14 +1285,14 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // launch.  BMO_FUSE=1 restores one launch per bounce level.
     int fuse_max = 1;
     if (KIND != BMO_BEAM_GAUSSIAN) {
-        fuse_max = 4;
-        if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(4, atoi(e)));
+        fuse_max = MAX_FUSE;  // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5
+        if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(MAX_FUSE, atoi(e)));
     }
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
     while (cur.count > 0) {
         const int64_t m = cur.count;
         const int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
-        Chunk nxt, inner[3];
+        Chunk nxt, inner[MAX_FUSE - 1];
         for (int q = 0; q + 1 < n_fuse; ++q) {
             if ((rc = new_chunk(m, inner[q]))) return rc;
             inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
@@ -1304,7 +1305,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.use_lds = use_lds;
         P.cur = cur;
         P.nxt = nxt;
-        for (int q = 0; q < 3; ++q) P.inner[q] = q + 1 < n_fuse ? inner[q] : Chunk{nullptr, nullptr, 0, 0};
+        for (int q = 0; q < MAX_FUSE - 1; ++q) P.inner[q] = q + 1 < n_fuse ? inner[q] : Chunk{nullptr, nullptr, 0, 0};
         P.n_fuse = n_fuse;
         P.ctr = d_ctr;
         P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
@@ -1747,6 +1748,18 @@ int bmo_result_timing(bmo_trace_result* r, double* k, double* t, int32_t* n) {
     if (k) *k = r->kernel_ms;
     if (t) *t = r->total_ms;
     if (n) *n = r->n_steps;
+    return BMO_OK;
+}
+
+int bmo_result_counts(bmo_trace_result* r, int64_t* calls, int64_t* records, int64_t* nodes, int64_t* hits) {
+    if (!r) return fail(BMO_ERR_INVALID, "null result");
+    if (calls) *calls = (int64_t)r->calls;
+    if (records) *records = r->n_records;
+    if (nodes) *nodes = r->n_nodes;
+    if (hits) {
+        *hits = 0;
+        for (int d = 0; d < r->n_detectors; ++d) *hits += r->det_count[d];
+    }
     return BMO_OK;
 }
 

@@ -269,12 +269,14 @@ class Engine:
         abi.check(self.lib, self.lib.bmo_result_copy_hits(res, slot, C.c_void_p(dst_device_ptr), max_hits), "bmo_result_copy_hits")
 
     def result_counts(self, res):
-        """(n_intersect_calls, n_records, n_nodes, n_steps, det_counts) without downloading the segment log."""
-        ms, tot, nl = self.result_timing(res)
-        cnt = []
-        for slot in range(len(self.scene.detectors)):
-            cnt.append(self.result_device_hits(res, slot)[1])
-        return cnt
+        """Per-detector hit counts without downloading anything."""
+        return [self.result_device_hits(res, slot)[1] for slot in range(len(self.scene.detectors))]
+
+    def result_size(self, res):
+        """bmo_result_counts: (reference intersect3d calls, segments, beams, detector hits) without downloading the solution."""
+        c, r, n, h = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        abi.check(self.lib, self.lib.bmo_result_counts(res, C.byref(c), C.byref(r), C.byref(n), C.byref(h)), "bmo_result_counts")
+        return c.value, r.value, n.value, h.value
 
     def free_result(self, res):
         self.lib.bmo_result_free(res)

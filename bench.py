@@ -155,11 +155,8 @@ def main():
         dt = float(tmax.item())
 
     # workload counters of ONE step (identical every step: the trace is deterministic)
-    v = eng.result_view(last)
-    calls, nrec, nnodes = v.n_intersect_calls, v.n_records, v.n_nodes
-    bounces = int(np.isfinite(v.rec[7]).sum())  # records whose ray was traced to an intersection + interaction
+    calls, nrec, nnodes, hits = eng.result_size(last)  # bmo_result_counts: nothing is downloaded
     traced = int(nrec)  # every record is one tracing_step
-    hits = int(v.det_count.sum())
     eng.free_result(last)
     if world > 1:
         agg = torch.tensor([calls, traced, hits, n_local], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

@@ -235,7 +235,7 @@ typedef struct bmo_trace_result_view {
     int64_t n_records;
     int64_t n_intersect_calls;  /* intersect3d(object|hint shape, ray) calls the reference
                                    algorithm performs for this trace (BASELINE metric) */
-    int32_t n_steps;            /* step-kernel launches (each advances every active beam by up to 4 bounces) */
+    int32_t n_steps;            /* step-kernel launches (each advances every active beam by up to 8 bounces) */
     int32_t beam_kind;
     int32_t rec_planes;         /* planes per record                                 */
     int32_t n_detectors;
@@ -293,6 +293,8 @@ int bmo_result_device_hits(bmo_trace_result* res, int32_t detector, const double
 int bmo_result_copy_hits(bmo_trace_result* res, int32_t detector, double* dst, int64_t max_hits);
 /* Kernel timing of the last trace: sum over step-kernel launches, HIP events on the trace stream. */
 int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* total_ms, int32_t* n_launches);
+/* Size of the solution without downloading it: reference intersect3d calls, segments, beams (tree nodes), detector hits. */
+int bmo_result_counts(bmo_trace_result* res, int64_t* n_intersect_calls, int64_t* n_records, int64_t* n_nodes, int64_t* n_hits);
 /* Materialise host views (downloads + canonical ordering of the segment log). */
 int bmo_result_view(bmo_trace_result* res, bmo_trace_result_view* view);
 int bmo_result_free(bmo_trace_result* res);
