@@ -162,3 +162,33 @@ def test_max_beams_limit(engine_ok):
                     eng.trace(bundle, 100)
         finally:
             eng.close()
+
+
+def test_concurrent_host_threads(engine_ok, oracle):
+    """include/bmo.h "Threading": trace calls may come from several host threads (they take turns on a device), one scene may be
+    shared; every thread gets its own, correct solution."""
+    import threading
+
+    system, _ = c2_scene()
+    bundles = [c2_bundle(2048 + 512 * i) for i in range(4)]
+    scene = bmo.CompiledScene(system, bundles[0].lambdas)
+    refs = [oracle.trace(scene, b, 100, threads=8) for b in bundles]
+    eng = bmo.Engine(scene, 0)  # one scene handle shared by all threads
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = eng.trace(bundles[i], 100)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    eng.close()
+    assert not errs, errs
+    for i in range(4):
+        compare(out[i], refs[i], 0.0, "thread %d" % i)
