@@ -47,7 +47,7 @@ def test_c2_bit_exact(engine_ok, oracle):
     assert got.det_count.sum() > 0
 
 
-@pytest.mark.parametrize("r_max", [1, 2, 3, 10])
+@pytest.mark.parametrize("r_max", [-3, 0, 1, 2, 3, 10])
 def test_r_max_cap(engine_ok, oracle, r_max):
     system, _ = c2_scene()
     got, ref = run_both(oracle, system, c2_bundle(256), r_max=r_max)
@@ -192,3 +192,53 @@ def test_concurrent_host_threads(engine_ok, oracle):
     assert not errs, errs
     for i in range(4):
         compare(out[i], refs[i], 0.0, "thread %d" % i)
+
+
+def test_argument_validation(engine_ok):
+    """Bad descriptors come back as BMO_ERR_INVALID with a message, never as a fault on the device."""
+    import ctypes as C
+
+    from bmo_amd import abi
+    from bmo_amd.system import make_batch
+
+    lib = engine_ok
+    system, _ = c1_scene()
+    bundle = c1_bundle(16)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    eng = bmo.Engine(scene, 0)
+    try:
+        o = eng.opts(100)
+        res = C.c_void_p()
+
+        def call(batch, opts=o):
+            return lib.bmo_trace(eng.handle, C.byref(batch), C.byref(opts), C.byref(res))
+
+        batch, keep = make_batch(scene, bundle)
+        assert call(batch) == 0
+        lib.bmo_result_free(res)
+        batch.kind = 7
+        assert call(batch) == -1 and b"kind" in lib.bmo_last_error()
+        batch, keep = make_batch(scene, bundle)
+        batch.n_planes -= 1
+        assert call(batch) == -1 and b"plane" in lib.bmo_last_error()
+        batch, keep = make_batch(scene, bundle)
+        batch.n = -5
+        assert call(batch) == -1
+        batch, keep = make_batch(scene, bundle)
+        idx = np.full(bundle.n, 3, dtype=np.int32)  # only one wavelength in this scene
+        batch.lambda_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
+        assert call(batch) == -1 and b"lambda" in lib.bmo_last_error()
+        batch, keep = make_batch(scene, bundle)
+        bad = eng.opts(100)
+        bad.device = 99
+        assert call(batch, bad) == -1 and b"device" in lib.bmo_last_error()
+        assert lib.bmo_trace(None, C.byref(batch), C.byref(o), C.byref(res)) == -1
+        # retrace against a batch of another size / kind
+        assert call(batch) == 0
+        prev = C.c_void_p(res.value)
+        other, keep2 = make_batch(scene, c1_bundle(8))
+        out = C.c_void_p()
+        assert lib.bmo_retrace(eng.handle, C.byref(other), prev, C.byref(o), C.byref(out)) == -1 and b"retrace" in lib.bmo_last_error()
+        lib.bmo_result_free(prev)
+    finally:
+        eng.close()
