@@ -1009,6 +1009,8 @@ struct bmo_trace_result {
     int abi_planes = 0;
     // device state
     std::vector<std::unique_ptr<DevBuf>> arena;  // chunk storage
+    int64_t view_records = 0;
+    bool has_log = true;                         // false: solved with record_segments = 0, only beams and detector hits were kept
     std::vector<Chunk> chunks;
     DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, n_aux, order, det_data, det_node;
     DevBuf n_old;  // retrace runs only (NodeArrays::old)
@@ -1029,6 +1031,7 @@ namespace {
 // OldSolution tables of `prev` (device arrays keyed by prev's node ids), built once per solution.
 int build_retrace_tables(bmo_trace_result* prev, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(prev->rt_mu);
+    if (!prev->has_log) return fail(BMO_ERR_INVALID, "retrace: the previous solution was solved with record_segments = 0 (no segment log to re-walk)");
     if (prev->rt_built) return BMO_OK;
     const int64_t nn = prev->n_nodes, nr = prev->n_records;
     if (nr >= (int64_t)1 << 31) return fail(BMO_ERR_UNSUPPORTED, "retrace: previous solution has more than 2^31 segments");
@@ -1192,10 +1195,26 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     const size_t rec_bytes = (size_t)L::ND * 8 + (size_t)NI * 4;
     size_t block_bytes = std::max<size_t>((size_t)n * rec_bytes * 6, (size_t)1 << 20);
     size_t top = 0;  // offset in the last block
+    // record_segments = 0: the log is not kept — every chunk gets its own pool block and goes back to the pool as soon as its level
+    // is done, so a solve holds two levels instead of all of them (beams, detector hits and counts are kept as always)
+    const bool keep_log = opts->record_segments != 0;
+    R->has_log = keep_log;
     auto new_chunk = [&](int64_t cap, Chunk& c) -> int {
         cap = std::max<int64_t>(cap, 1);
         const size_t cap_al = ((size_t)cap + 1) & ~(size_t)1;  // keep int planes 8-byte aligned
         const size_t need = cap_al * rec_bytes;
+        if (!keep_log) {
+            auto b = std::make_unique<DevBuf>();
+            int r = b->alloc(need);
+            if (r) return r;
+            char* base = static_cast<char*>(b->p);
+            c.d = reinterpret_cast<double*>(base);
+            c.i = reinterpret_cast<int32_t*>(base + cap_al * (size_t)L::ND * 8);
+            c.cap = (int64_t)cap_al;
+            c.count = 0;
+            R->arena.push_back(std::move(b));
+            return BMO_OK;
+        }
         if (R->arena.empty() || top + need > R->arena.back()->bytes) {
             auto b = std::make_unique<DevBuf>();
             int r = b->alloc(std::max(block_bytes, need));
@@ -1210,6 +1229,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         c.count = 0;
         top += need;
         return BMO_OK;
+    };
+    auto drop_chunk = [&](const Chunk& c) {  // record_segments = 0 only
+        for (size_t q = 0; q < R->arena.size(); ++q)
+            if (R->arena[q]->p == (void*)c.d) {
+                R->arena.erase(R->arena.begin() + (long)q);
+                return;
+            }
     };
     auto shrink_last = [&](Chunk& c, int64_t used) {
         // planes are strided by cap, so the chunk keeps its footprint; nothing to return.
@@ -1294,6 +1320,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         const int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
         Chunk nxt, inner[MAX_FUSE - 1];
         for (int q = 0; q + 1 < n_fuse; ++q) {
+            if (!keep_log && q > 0) {
+                inner[q] = inner[0];  // nobody reads the log: a lane's in-place record is dead once it has been read back, one chunk serves all levels
+                continue;
+            }
             if ((rc = new_chunk(m, inner[q]))) return rc;
             inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
         }
@@ -1331,8 +1361,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
-        R->chunks.push_back(cur);
-        for (int q = 0; q + 1 < n_fuse; ++q) R->chunks.push_back(inner[q]);
+        if (keep_log) {
+            R->chunks.push_back(cur);
+            for (int q = 0; q + 1 < n_fuse; ++q) R->chunks.push_back(inner[q]);
+        } else {  // the launch above has completed (counter read-back): its input and in-place levels are dead
+            drop_chunk(cur);
+            if (n_fuse > 1) drop_chunk(inner[0]);
+        }
         shrink_last(nxt, (int64_t)produced);
         keep_ratio = (double)std::min<unsigned long long>(produced, (unsigned long long)m) / (double)m;
         n_nodes = (int64_t)h_ctr.node_count;
@@ -1809,13 +1844,15 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
             if (p >= 0 && (r->h_first_child[p] < 0 || i < r->h_first_child[p])) r->h_first_child[p] = (int32_t)i;
         }
         if (acc != nr) return fail(BMO_ERR_INTERNAL, "segment count mismatch");
+        r->view_records = r->has_log ? nr : 0;
         const int P = r->abi_planes;
         int64_t tot = 0;
         for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
-        if ((rc = r->h_rec.alloc((size_t)P * nr * 8)) || (rc = r->h_rec_obj.alloc((size_t)nr * 4)) || (rc = r->h_rec_shape.alloc((size_t)nr * 4)) ||
+        const int64_t vr = r->view_records;
+        if ((rc = r->h_rec.alloc((size_t)P * vr * 8)) || (rc = r->h_rec_obj.alloc((size_t)vr * 4)) || (rc = r->h_rec_shape.alloc((size_t)vr * 4)) ||
             (rc = r->h_det.alloc((size_t)tot * 72)) || (rc = r->h_det_node.alloc((size_t)tot * 4)))
             return rc;
-        if (nr > 0) {
+        if (nr > 0 && r->has_log) {
             // re-order on the device, then one copy per table
             std::vector<int32_t> dst_base(nn);
             for (int64_t i = 0; i < nn; ++i) dst_base[order[i]] = r->h_first_rec[i];
@@ -1844,7 +1881,7 @@ int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
     std::memset(v, 0, sizeof *v);
     v->n_roots = r->n_roots;
     v->n_nodes = r->n_nodes;
-    v->n_records = r->n_records;
+    v->n_records = r->view_records;  // 0 when the log was not kept (record_segments = 0); bmo_result_counts still reports the count
     v->n_intersect_calls = (int64_t)r->calls;
     v->n_steps = r->n_steps;
     v->beam_kind = r->kind;

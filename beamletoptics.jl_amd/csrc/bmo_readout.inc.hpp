@@ -307,6 +307,7 @@ extern "C" int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, 
     if (rows % 3) return fail(BMO_ERR_INVALID, "bmo_photodetector_field: slot does not hold photodetector records");
     const int64_t H = rows / 3;
     if (H == 0) return BMO_OK;
+    if (!res->has_log) return fail(BMO_ERR_INVALID, "bmo_photodetector_field: the solution was solved with record_segments = 0 (gauss_parameters needs the beamlets' segments)");
     HIP_TRY(hipSetDevice(res->device));
     const int64_t nn = res->n_nodes, n_pts = (int64_t)nx * ny;
     int rc;

@@ -211,7 +211,11 @@ typedef struct bmo_ray_batch {
 typedef struct bmo_trace_opts {
     int32_t r_max;              /* solve_system! default 100 (System.jl:444)         */
     int32_t device;             /* HIP device ordinal                                */
-    int32_t record_segments;    /* 1: keep the full segment log (reference behaviour) */
+    int32_t record_segments;    /* 1: keep the full segment log (reference behaviour).  0: keep only the beam tree, statuses,
+                                   counts and detector hits - a solve then holds three bounce levels in HBM instead of all
+                                   of them (8x less on config C2), for spot diagrams / PSFs of very large bundles; the view of
+                                   such a result reports n_records = 0, and it cannot be retraced or read out as a
+                                   Photodetector field (both need the segments): BMO_ERR_INVALID.                     */
     int32_t max_beams;          /* 0: no limit (reference behaviour).  > 0: stop with BMO_ERR_LIMIT once the solve holds more
                                    than this many beams (tree nodes).  A splitter facing a mirror multiplies beams on every
                                    pass; solve_system! recurses until memory runs out on such a system, and so does this

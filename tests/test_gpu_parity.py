@@ -242,3 +242,34 @@ def test_argument_validation(engine_ok):
         lib.bmo_result_free(prev)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("kind", ["ray", "gauss"])
+def test_record_segments_off(engine_ok, oracle, kind):
+    """bmo_trace_opts.record_segments = 0: beam tree, statuses, counts and detector hits as with the log; the log itself is not
+    kept (view reports no records), and what needs it (retrace, Photodetector field) refuses."""
+    import ctypes as C
+
+    system, _ = c2_scene()
+    bundle = c2_bundle(3000) if kind == "ray" else c3_bundle(600)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    ref = oracle.trace(scene, bundle, 100, threads=8)
+    eng = bmo.Engine(scene, 0)
+    try:
+        dev = eng.upload(bundle)
+        full = eng.trace_device(dev, 100)
+        lean = eng.trace_device(dev, 100, record_segments=False)
+        assert eng.result_size(lean) == eng.result_size(full) == (ref.n_intersect_calls, ref.n_records, ref.n_nodes, int(ref.det_count.sum()))
+        vf, vl = eng.result_view(full), eng.result_view(lean)
+        for name in ("node_root", "node_parent", "node_first_child", "node_nseg", "node_status", "det_count", "det_offset", "det_node"):
+            assert np.array_equal(getattr(vf, name), getattr(vl, name)), name
+        assert np.array_equal(vf.det_data, vl.det_data) and np.array_equal(vf.node_aux, vl.node_aux, equal_nan=True)
+        assert vl.n_records == 0 and vl.rec.size == 0 and vf.n_records == ref.n_records
+        out = C.c_void_p()
+        o = eng.opts(100)
+        assert eng.lib.bmo_retrace_device(eng.handle, dev, lean, C.byref(o), C.byref(out)) == -1 and b"record_segments" in eng.lib.bmo_last_error()
+        eng.free_result(full)
+        eng.free_result(lean)
+        eng.free_batch(dev)
+    finally:
+        eng.close()
