@@ -502,6 +502,70 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
 
 
 // ------------------------------------------------------------------ GaussianBeamlet step (System.jl:274-318)
+// The beamlet record of lane j as gauss_step_rec sees it: rays come out of the chunk when a march starts, hits go back into it when
+// the march ends (they are part of the log anyway), the accumulators are read after the marches.
+struct GaussRecDev {
+    double* D;
+    const int32_t* I;
+    const NodeArrays& nodes;
+    int64_t cap, j;
+    int32_t node;
+    __device__ RayS ray(int r) const {
+        const int64_t b = 11 * (int64_t)r;
+        RayS x;
+        x.pos = {D[(b + 0) * cap + j], D[(b + 1) * cap + j], D[(b + 2) * cap + j]};
+        x.dir = {D[(b + 3) * cap + j], D[(b + 4) * cap + j], D[(b + 5) * cap + j]};
+        x.n = D[(b + 6) * cap + j];
+        return x;
+    }
+    __device__ void put_hit(int r, const Hit& X) const {
+        const int64_t b = 11 * (int64_t)r;
+        D[(b + 7) * cap + j] = X.t;
+        D[(b + 8) * cap + j] = X.n.x;
+        D[(b + 9) * cap + j] = X.n.y;
+        D[(b + 10) * cap + j] = X.n.z;
+    }
+    __device__ Hit hit(int r) const {
+        const int64_t b = 11 * (int64_t)r;
+        Hit X;
+        X.t = D[(b + 7) * cap + j];
+        X.n = {D[(b + 8) * cap + j], D[(b + 9) * cap + j], D[(b + 10) * cap + j]};
+        X.obj = X.shape = -1;
+        return X;
+    }
+    __device__ void clear_hits() const {
+        const Hit X = no_hit();
+        put_hit(0, X);
+        put_hit(1, X);
+        put_hit(2, X);
+    }
+    __device__ int32_t hint_obj() const { return I[I_HOBJ * cap + j]; }
+    __device__ int32_t hint_shape() const { return I[I_HSHAPE * cap + j]; }
+    __device__ GaussIn load() const {
+        GaussIn g;
+        g.c = ray(0);
+        g.w = ray(1);
+        g.d = ray(2);
+        g.hint_obj = g.hint_shape = -1;  // consumed before the marches
+        g.lenA = D[33 * cap + j];
+        g.lenB = D[34 * cap + j];
+        g.oplC = D[35 * cap + j];
+        g.oplW = D[36 * cap + j];
+        g.oplD = D[37 * cap + j];
+        g.li = nodes.li[node];
+        g.lambda = nodes.lambda[node];
+        g.l0 = nodes.aux[(int64_t)node * 4 + 0];
+        g.w0 = nodes.aux[(int64_t)node * 4 + 1];
+        g.E0 = {nodes.aux[(int64_t)node * 4 + 2], nodes.aux[(int64_t)node * 4 + 3]};
+        return g;
+    }
+};
+// retrace: a beamlet that re-walks its stored path without a probe starts without a hint
+struct GaussRecDevNoHint : GaussRecDev {
+    __device__ int32_t hint_obj() const { return -1; }
+    __device__ int32_t hint_shape() const { return -1; }
+};
+
 template <bool LDS, bool ASPH, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -513,7 +577,6 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
     const bool valid = j < m;
     bool survive = false, split = false;
     int32_t node = -1, k = 0;
-    GaussIn g;
     GaussOut o;
     o.outcome = OUT_MISS;
     uint32_t calls = 0;
@@ -525,38 +588,27 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
         node = I[I_NODE * cap + j];
         k = I[I_K * cap + j];
         const int32_t flags = I[I_FLAGS * cap + j];
-        auto ld = [&](int base, RayS& r) {
-            r.pos = {D[(base + 0) * cap + j], D[(base + 1) * cap + j], D[(base + 2) * cap + j]};
-            r.dir = {D[(base + 3) * cap + j], D[(base + 4) * cap + j], D[(base + 5) * cap + j]};
-            r.n = D[(base + 6) * cap + j];
-        };
-        ld(0, g.c);
-        ld(11, g.w);
-        ld(22, g.d);
-        g.hint_obj = I[I_HOBJ * cap + j];
-        g.hint_shape = I[I_HSHAPE * cap + j];
-        g.lenA = D[33 * cap + j];
-        g.lenB = D[34 * cap + j];
-        g.oplC = D[35 * cap + j];
-        g.oplW = D[36 * cap + j];
-        g.oplD = D[37 * cap + j];
-        g.li = P.nodes.li[node];
-        g.lambda = P.nodes.lambda[node];
-        g.l0 = P.nodes.aux[(int64_t)node * 4 + 0];
-        g.w0 = P.nodes.aux[(int64_t)node * 4 + 1];
-        g.E0 = {P.nodes.aux[(int64_t)node * 4 + 2], P.nodes.aux[(int64_t)node * 4 + 3]};
         int status = 0;
-        o.Xc = o.Xw = o.Xd = no_hit();
+        o.hit_obj = o.hit_shape = -1;
+        o.det_slot = -1;
         o.det = P.nodes.hit + (int64_t)node * 27;  // a detector hit ends the beamlet: its records go straight to the node's slot
+        bool no_hint = false;
         if (RETR) {
             rt = retrace_lane(P, node, k);
-            if (rt.old >= 0 && !rt.probe) g.hint_obj = g.hint_shape = -1;
+            no_hint = rt.old >= 0 && !rt.probe;
         }
+        GaussRecDev rec{D, I, P.nodes, cap, j, node};
         if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;
+            rec.clear_hits();
         } else {
             ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
-            gauss_step<ASPH, RETR>(S, g, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+            if (RETR && no_hint) {
+                GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node}};
+                gauss_step_rec<ASPH, RETR>(S, rn, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+            } else {
+                gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+            }
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
             else if (o.outcome == OUT_SPLIT) {
@@ -564,17 +616,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
                 status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
             } else if (o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
         }
-        auto st = [&](int base, const Hit& X) {
-            D[(base + 7) * cap + j] = X.t;
-            D[(base + 8) * cap + j] = X.n.x;
-            D[(base + 9) * cap + j] = X.n.y;
-            D[(base + 10) * cap + j] = X.n.z;
-        };
-        st(0, o.Xc);
-        st(11, o.Xw);
-        st(22, o.Xd);
-        I[I_OBJ * cap + j] = o.Xc.obj;
-        I[I_SHAPE * cap + j] = o.Xc.shape;
+        I[I_OBJ * cap + j] = o.hit_obj;
+        I[I_SHAPE * cap + j] = o.hit_shape;
         if (RETR) {
             still = rt.old >= 0 && rt.probe && !rt.missed;
             old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
@@ -645,8 +688,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
                 P.nodes.parent[c] = node;
                 P.nodes.nseg[c] = 1;
                 P.nodes.status[c] = 0;
-                P.nodes.li[c] = g.li;
-                P.nodes.lambda[c] = g.lambda;
+                P.nodes.li[c] = P.nodes.li[node];
+                P.nodes.lambda[c] = P.nodes.lambda[node];
                 P.nodes.hit_det[c] = -1;
                 P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
                 P.nodes.aux[c * 4 + 0] = o.child_l0;

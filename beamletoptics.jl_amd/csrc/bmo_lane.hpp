@@ -1341,7 +1341,8 @@ struct GaussIn {
 };
 struct GaussOut {
     int outcome, status;
-    Hit Xc, Xw, Xd;
+    Hit Xc, Xw, Xd;                // filled by the struct-backed wrapper only
+    int32_t hit_obj, hit_shape;    // object / shape the chief ray hit (-1: none)
     int32_t hint_obj, hint_shape;
     RayS nc, nw, nd;  // next segment, or transmitted child
     RayS rc, rw, rd;  // reflected child
@@ -1448,29 +1449,43 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
 // (retrace_system! System.jl:360-375; all three are always evaluated), and the stored path holds only if all three still
 // hit the same shape (:377-392).  Otherwise the beamlet is cut here and trace_system! goes on from these rays without a
 // hint (System.jl:274-318) when `fresh_allowed`.
-template <bool ASPH, bool RETR = false>
-BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
-                       bool fresh_allowed = true, bool* probe_missed = nullptr) {
+//
+// The beamlet's record is reached through `Rec` (ray(r), put_hit(r, X), hit(r), clear_hits(), hint_obj(), hint_shape(), load()):
+// a ray is fetched when its march starts and its hit is put back when the march ends, so nothing of the beamlet but a few integers
+// is live across the three sphere-tracing marches.  On the GPU the backing store is the record itself (HBM / L2); held in
+// registers, the 3 rays + 3 hits were spilled around every march (1.5 KB of scratch per lane, 5 x the algorithmic HBM traffic).
+template <bool ASPH, bool RETR, class Rec>
+BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
+                           bool fresh_allowed = true, bool* probe_missed = nullptr) {
     o.outcome = OUT_MISS;
     o.status = 0;
     o.hint_obj = o.hint_shape = -1;
     o.det_slot = -1;
     o.n_det = 0;
-    o.Xc = o.Xw = o.Xd = no_hit();
+    o.hit_obj = o.hit_shape = -1;
+    rec.clear_hits();
     // chief, waist, divergence in that order; stop at the first ray without intersection (System.jl:283-296)
     bool all_hit = true;
-    int32_t hint_obj = g.hint_obj, hint_shape = g.hint_shape;
+    int32_t hint_obj = rec.hint_obj(), hint_shape = rec.hint_shape();
+    int32_t sh0 = -1, sh1 = -1, sh2 = -1, ob0 = -1;
     BMO_NOUNROLL
     for (int phase = (RETR && probe) ? 0 : 1; phase < 2; ++phase) {
         const bool probing = RETR && phase == 0;
         all_hit = true;
+        sh0 = sh1 = sh2 = ob0 = -1;
         BMO_NOUNROLL
         for (int r = 0; r < 3; ++r) {
-            const RayS ray = pick_ray(r, g.c, g.w, g.d);
+            const RayS ray = rec.ray(r);
             Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, probing, probe_obj, false, nullptr);
-            if (r == 0) o.Xc = X;
-            else if (r == 1) o.Xw = X;
-            else o.Xd = X;
+            rec.put_hit(r, X);
+            if (r == 0) {
+                sh0 = X.shape;
+                ob0 = X.obj;
+            } else if (r == 1) {
+                sh1 = X.shape;
+            } else {
+                sh2 = X.shape;
+            }
             if (!probing && X.shape < 0) {
                 all_hit = false;
                 break;
@@ -1478,9 +1493,10 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
         }
         if (probing) {
             // the stored path holds only if all three rays still hit the same shape (System.jl:377-392)
-            if (o.Xc.shape >= 0 && o.Xw.shape >= 0 && o.Xd.shape >= 0 && o.Xc.shape == o.Xw.shape && o.Xw.shape == o.Xd.shape) break;
+            if (sh0 >= 0 && sh1 >= 0 && sh2 >= 0 && sh0 == sh1 && sh1 == sh2) break;
             if (probe_missed) *probe_missed = true;
-            o.Xc = o.Xw = o.Xd = no_hit();
+            rec.clear_hits();
+            sh0 = sh1 = sh2 = ob0 = -1;
             if (!fresh_allowed) {
                 o.status = BMO_NODE_RMAX;
                 return;
@@ -1488,44 +1504,51 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
             hint_obj = hint_shape = -1;
         }
     }
+    o.hit_obj = ob0;
+    o.hit_shape = sh0;
     if (!all_hit) {
         o.status = BMO_NODE_MISS;
         return;
     }
-    if (!(o.Xc.shape == o.Xw.shape && o.Xw.shape == o.Xd.shape)) {  // _beams_hits_same_shape Gaussian.jl:171-180
-        o.Xc = o.Xw = o.Xd = no_hit();
+    if (!(sh0 == sh1 && sh1 == sh2)) {  // _beams_hits_same_shape Gaussian.jl:171-180
+        rec.clear_hits();
+        o.hit_obj = o.hit_shape = -1;
         o.status = BMO_NODE_GAUSS_DIVERGED;
         return;
     }
-    const int32_t oid = o.Xc.obj;
+    const GaussIn g = rec.load();  // rays and accumulators, from here on
+    const Hit Xc = rec.hit(0);     // t and normal of the chief's hit
+    const double tw = rec.hit(1).t, td = rec.hit(2).t;
+    const int32_t oid = ob0;
     CObject& ob = S.objects[oid];
     if (ob.kind == BMO_OBJ_PHOTODETECTOR) {  // Photodetector.jl:69-107: record the hit (field read-out is a separate pass), stop
         o.det_slot = ob.detector;
         for (int c = 0; c < 27; ++c) o.det[c] = 0.0;
-        o.det[0] = fabs(dot3(g.c.dir, o.Xc.n));  // proj = abs(dot(d0, normal3d(ray_int)))
+        o.det[0] = fabs(dot3(g.c.dir, Xc.n));  // proj = abs(dot(d0, normal3d(ray_int)))
         o.n_det = 3;
         o.status |= BMO_NODE_DETECTED;
-        o.lenA = g.lenA + o.Xc.t;
-        o.lenB = g.lenB + o.Xc.t;
-        o.oplC = g.oplC + o.Xc.t * g.c.n;
-        o.oplW = g.oplW + o.Xw.t * g.w.n;
-        o.oplD = g.oplD + o.Xd.t * g.d.n;
+        o.lenA = g.lenA + Xc.t;
+        o.lenB = g.lenB + Xc.t;
+        o.oplC = g.oplC + Xc.t * g.c.n;
+        o.oplW = g.oplW + tw * g.w.n;
+        o.oplD = g.oplD + td * g.d.n;
         o.outcome = OUT_STOP;
         return;
     }
-    const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && o.Xc.shape == ob.shape[1]) ||
-                         (ob.kind == BMO_OBJ_CUBE_BS && o.Xc.shape == ob.shape[2]);
+    const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && sh0 == ob.shape[1]) || (ob.kind == BMO_OBJ_CUBE_BS && sh0 == ob.shape[2]);
     // every sub-beam interacts with the object found by the CHIEF ray (System.jl:306-309, Gaussian.jl:124-135)
     bool all_continue = true;
+    const int entering_hint = dot3(g.c.dir, Xc.n) < 0 ? 1 : 0;
     BMO_NOUNROLL
     for (int r = 0; r < 3; ++r) {
         const RayS ray = pick_ray(r, g.c, g.w, g.d);
-        Hit X = pick_hit(r, o.Xc, o.Xw, o.Xd);
+        Hit X = rec.hit(r);
         X.obj = oid;
+        X.shape = sh0;
         const double opl = r == 0 ? g.oplC : (r == 1 ? g.oplW : g.oplD);
         StepOut so;
         so.status = 0;
-        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, dot3(g.c.dir, o.Xc.n) < 0 ? 1 : 0);
+        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, entering_hint);
         o.status |= so.status;
         if (r == 0) {
             o.nc = so.next;
@@ -1551,11 +1574,11 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
         const int want = coating ? OUT_SPLIT : OUT_CONTINUE;
         if (so.outcome != want) all_continue = false;
     }
-    o.oplC = g.oplC + o.Xc.t * g.c.n;
-    o.oplW = g.oplW + o.Xw.t * g.w.n;
-    o.oplD = g.oplD + o.Xd.t * g.d.n;
-    o.lenA = g.lenA + o.Xc.t;
-    o.lenB = g.lenB + o.Xc.t;
+    o.oplC = g.oplC + Xc.t * g.c.n;
+    o.oplW = g.oplW + tw * g.w.n;
+    o.oplD = g.oplD + td * g.d.n;
+    o.lenA = g.lenA + Xc.t;
+    o.lenB = g.lenB + Xc.t;
     if (!all_continue) {
         o.outcome = OUT_STOP;
         return;
@@ -1565,17 +1588,39 @@ BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32
         return;
     }
     // splitter: ThinBeamsplitter.jl:117-168 (+ PlateBeamsplitter.jl:230-275, CubeBeamsplitter.jl:94-121 via interact's split modes)
-    const double t_total = (g.lenA + o.Xc.t) + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
+    const double t_total = (g.lenA + Xc.t) + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
     const double w0 = gauss_w0_at(g, t_total, g.lenB);
     o.child_w0 = w0;
     o.child_l0 = t_total;
     const double ratio = g.w0 / w0;
     o.Et = cmulr(rmul(ob.transmittance, g.E0), ratio);
     o.Er = cmulr(rmul(ob.reflectance, g.E0), ratio);
-    const double df = dot3(g.c.dir, o.Xc.n);
+    const double df = dot3(g.c.dir, Xc.n);
     const cx ph = df < 0 ? cx{-1.0, 1.2246467991473532e-16} : cx{1.0, 0.0};  // exp(im*π) | exp(im*0)
     o.Er = cmul(o.Er, ph);
     o.outcome = OUT_SPLIT;
+}
+
+// struct-backed record (host emulator, tests): same code path as the device's memory-backed one
+struct GaussRecLocal {
+    const GaussIn& g;
+    Hit X[3];
+    BMO_HD RayS ray(int r) const { return pick_ray(r, g.c, g.w, g.d); }
+    BMO_HD void put_hit(int r, const Hit& x) { X[r] = x; }
+    BMO_HD Hit hit(int r) const { return X[r]; }
+    BMO_HD void clear_hits() { X[0] = X[1] = X[2] = no_hit(); }
+    BMO_HD int32_t hint_obj() const { return g.hint_obj; }
+    BMO_HD int32_t hint_shape() const { return g.hint_shape; }
+    BMO_HD GaussIn load() const { return g; }
+};
+template <bool ASPH, bool RETR = false>
+BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
+                       bool fresh_allowed = true, bool* probe_missed = nullptr) {
+    GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}};
+    gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, probe, probe_obj, fresh_allowed, probe_missed);
+    o.Xc = rec.X[0];
+    o.Xw = rec.X[1];
+    o.Xd = rec.X[2];
 }
 
 }  // namespace bmo
