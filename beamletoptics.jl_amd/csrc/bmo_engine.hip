@@ -1464,7 +1464,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         };
         const int bits_depth = bits_for(h_ctr.max_depth), bits_root = bits_for((unsigned long long)std::max<int64_t>(n - 1, 0));
         DevBuf keys_in, keys_out, vals_out, tmp;
-        static const bool force_deep = std::getenv("BMO_FORCE_DEEP_ORDER") != nullptr;  // test hook: take the deep-tree path for any tree
+        const bool force_deep = std::getenv("BMO_FORCE_DEEP_ORDER") != nullptr;  // test hook: take the deep-tree path for any tree
         if (h_ctr.max_depth <= (unsigned long long)MAX_PATH_LEVELS && !force_deep) {
             const int bits_path = (int)h_ctr.max_depth;  // one bit per level
             const int bits = bits_root + bits_depth + bits_path;

@@ -192,6 +192,9 @@ def test_engine_equals_oracle_on_random_scenes(oracle, seed, kind):
 # A cube splitter between two mirrors, one tilted by 0.003 deg: every pass through the cube sheds one beam sideways and the cavity beam
 # walks off only after ~90 passes, so each root's beam tree is ~87 levels deep although it has only ~170 beams.  The node order
 # (bundle order x breadth-first per tree) must hold for any depth (a random sweep found the engine's old 26 / 64-level key limits).
+DEEP = -1  # marker for the cavity scene in mixed case lists
+
+
 def cavity_case(kind, n):
     a = bmo.RoundPlanoMirror(30 * mm, 5 * mm)
     bmo.translate3d(a, [0, -30 * mm, 0])
@@ -309,3 +312,59 @@ def test_engine_photodetector_field_on_random_scenes(oracle, seed):
     assert np.abs(fg - fa).max() <= 1e-9 * max(peak, 1e-300)
     gsol.free()
     osol.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------- kernel variants
+VARIANTS = [{"BMO_NO_LDS": "1"}, {"BMO_FUSE": "1"}, {"BMO_FUSE": "3"}, {"BMO_FORCE_DEEP_ORDER": "1"}, {"BMO_NO_LDS": "1", "BMO_FUSE": "2"}]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_engine_variants_on_random_scenes(oracle, monkeypatch, env):
+    """The engine's other code paths — scene tables read from global memory instead of LDS (what a scene > 120 KB gets), other
+    fused-level counts, the level-by-level node ordering of deep trees — on a slice of the random scenes, incl. a retrace."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for seed, kind in CASES[0:96:8] + [(DEEP, "ray")]:
+        if seed == DEEP:
+            scene, bundle = cavity_case("ray", 64)
+        else:
+            scene, bundle = _case(seed, kind, 1024 if kind == "ray" else 256)
+        eng = bmo.Engine(scene, 0, max_beams=_limit(bundle.n))
+        try:
+            got = _engine_first(lambda: eng.trace(bundle, R_MAX))
+        finally:
+            eng.close()
+        ref = oracle.trace(scene, bundle, R_MAX, threads=16)
+        compare(got, ref, _tol(kind), "variant %s seed %s %s" % (env, seed, kind))
+    scene0, scene1, bundle = _retrace_case(401, "ray", 1024)
+    g0, h0 = bmo.system._engine_solve(scene0, bundle, R_MAX, None)
+    g1, h1 = bmo.system._engine_solve(scene1, bundle, R_MAX, h0)
+    a0, sol = oracle.trace(scene0, bundle, R_MAX, threads=16, keep=True)
+    compare(g1, oracle.trace(scene1, bundle, R_MAX, threads=16, prev=sol), 0.0, "variant %s retrace" % env)
+    h0.free()
+    h1.free()
+
+
+@pytest.mark.gpu
+def test_scene_larger_than_lds(oracle):
+    """A 2 400-triangle disc mirror makes the scene tables 190 KB: they stay in global memory (LDS holds 160 KB)."""
+    mirror = bmo.Mirror(bmo.CircularFlatMesh(20 * mm, 2400))
+    bmo.xrotate3d(mirror, math.radians(20))
+    bmo.translate3d(mirror, [0, 60 * mm, 0])
+    lens = bmo.SphericalLens(60 * mm, -60 * mm, 6 * mm, D, 1.5)
+    det = bmo.Spotdetector(60 * mm)
+    bmo.xrotate3d(det, math.radians(90))
+    bmo.translate3d(det, [0, 0, -50 * mm])
+    system = bmo.System([lens, mirror, det])
+    bundle = disc_bundle(2048, [0, -20 * mm, 0], [0, 1, 0], 0.6 * D, jitter=0.01)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    assert scene.desc.n_tris > 2400
+    eng = bmo.Engine(scene, 0)
+    try:
+        got = eng.trace(bundle, R_MAX)
+    finally:
+        eng.close()
+    ref = oracle.trace(scene, bundle, R_MAX, threads=16)
+    assert int(ref.det_count.sum()) > 0
+    compare(got, ref, 0.0, "big scene")
