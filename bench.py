@@ -88,11 +88,12 @@ def main():
     n_local = args.rays
     n_global = n_local * world
 
-    def shard_bundle(n_tot, lo, hi):
-        b = c2_bundle(n_tot)
-        return bmo.RayBundle(b.kind, b.planes[:, lo:hi])
+    # Weak scaling: the global bundle is the concatenation, in rank order, of one complete C2 bundle per GPU (same disc and cone
+    # distribution, the cone directions drawn from seed + rank), so every rank traces the N = 1 workload and its contiguous shard
+    # keeps the reference's detector order.  Slicing ONE disc into rank-sized rings would give the ranks unequal work.
+    from scenes import SEED
 
-    bundle = shard_bundle(n_global, rank * n_local, (rank + 1) * n_local)  # contiguous shards keep reference order
+    bundle = c2_bundle(n_local, seed=SEED + rank)
     scene = bmo.CompiledScene(system, bundle.lambdas)
     eng = bmo.Engine(scene, device_ord if world > 1 else 0)
     dev_batch = eng.upload(bundle)
@@ -193,7 +194,7 @@ def main():
             "data": "synthetic",
             "rays_per_s": rays_all * args.steps / dt,
             "config": {
-                "workload": "1M geometric Rays (2^20 per GPU, Fibonacci disc + 0.25 rad cone, seed 20251003) through the 10-element "
+                "workload": "1M geometric Rays (2^20 per GPU, Fibonacci disc + 0.25 rad cone, seed 20251003 + rank) through the 10-element "
                             "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors; r_max=100; full segment log kept",
                 "rays_per_gpu": n_local, "elements": scene.n_objects, "shapes": len(scene.shape_list),
                 "segments_per_step": int(traced_all), "beam_nodes": int(nnodes), "detector_hits": int(hits_all),
@@ -208,13 +209,13 @@ def main():
                         "see DESIGN.md for the VALU-side accounting",
             },
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
             def strided(sample):
-                g = c2_bundle(n_global)
-                idx = (np.arange(sample) * (n_global // sample)).astype(np.int64)
+                g = c2_bundle(n_local)
+                idx = (np.arange(sample) * (n_local // sample)).astype(np.int64)
                 return bmo.RayBundle(g.kind, g.planes[:, idx])
 
-            out["cpu_baseline"] = cpu_baseline(scene, strided, min(args.cpu_sample, n_global), args.r_max)
+            out["cpu_baseline"] = cpu_baseline(scene, strided, min(args.cpu_sample, n_local), args.r_max)
         print(json.dumps(out))
     eng.free_batch(dev_batch)
     eng.close()

@@ -114,9 +114,9 @@ def c2_scene():
     return system, dict(bs=bs, det_t=det_t, det_r=det_r)
 
 
-def c2_bundle(n, lam=1.064e-6):
+def c2_bundle(n, lam=1.064e-6, seed=SEED):
     """Extended object 0.3 mm across at the miniscope's object plane, rays filling a 0.25 rad cone (NA ~ 0.25)."""
-    return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, lam=lam, e1=[1, 0, 0], cone=0.25)
+    return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, lam=lam, e1=[1, 0, 0], cone=0.25, seed=seed)
 
 
 # ------------------------------------------------------------------------------------ C4
