@@ -622,6 +622,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             still = rt.old >= 0 && rt.probe && !rt.missed;
             old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
             if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+            // a split before the end of the stored path: the reference sizes the children (w0, E0) with the stale tail still attached
+            // to the beamlet (gauss_parameters(gauss, length(gauss)), ThinBeamsplitter.jl:125); here they are evaluated at the split
+            if (split && still && k + 1 < rt.old_n) status |= BMO_NODE_RETRACE_STALE;
             if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
         }
         if (!survive) {

@@ -65,7 +65,11 @@ enum bmo_node_status {
     BMO_NODE_RETRACE_STALE = 512 /* retrace only: the stored beam had children, and the re-walk ended in a `nothing`
                                     interaction without reaching the splitter.  The reference then keeps the stale
                                     children untouched (System.jl:232-239 sets no cleanup flag); this library drops them
-                                    and raises this flag so the wrapper can fall back to the wrapped System. */
+                                    and raises this flag so the wrapper can fall back to the wrapped System.
+                                    Also raised when a GaussianBeamlet splits BEFORE the end of its stored path: the
+                                    reference then sizes the children (w0, E0) from gauss_parameters(gauss, length(gauss))
+                                    with the stale tail still attached (ThinBeamsplitter.jl:125); this library evaluates
+                                    them at the split point, as a fresh solve would. */
 };
 
 /* ------------------------------------------------------------------ shapes */

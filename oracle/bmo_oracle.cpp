@@ -1424,6 +1424,10 @@ bool retrace_gauss(Ctx& C, Node& g) {
         if (!gi.some) {
             g.status |= BMO_NODE_STOPPED;
             if (!g.children.empty() && !(g.status & BMO_NODE_SPLIT)) g.status |= BMO_NODE_RETRACE_STALE;
+            // a split before the end of the stored path: the children's w0 / E0 come from gauss_parameters(gauss, length(gauss)) with the
+            // stale tail still attached (ThinBeamsplitter.jl:125; the tail goes only after this loop).  Reproduced here; flagged because
+            // the engine, which has no stale tail, evaluates them at the split point.
+            if ((g.status & BMO_NODE_SPLIT) && n_c > i) g.status |= BMO_NODE_RETRACE_STALE;
             if (n_c > i) {
                 cleanup_tail = true;
                 cutoff = i;

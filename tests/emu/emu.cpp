@@ -411,6 +411,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             if (!keep_walking) nodes[r.node].old = -1;
             if (!survive) {
                 if (old_kids && r.o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
+                if (r.o.outcome == OUT_SPLIT && still && r.k + 1 < old_n) status |= BMO_NODE_RETRACE_STALE;  // the reference sizes the children with the stale tail
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
                 if (r.o.det_slot >= 0 && !(r.flags & 1)) nodes[r.node].hit_det = r.o.det_slot;
