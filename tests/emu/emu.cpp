@@ -26,6 +26,8 @@ struct NodeE {
     double lambda, hit[9];
     int old = -1;  // node of the previous solution this beam re-walks (retrace), -1 = fresh
 };
+struct BeamLimit {};
+
 // reference order of the beam nodes: bundle order x breadth-first order of each root's tree (the two children of a splitting beam are
 // created consecutively, transmitted first).  Any tree depth.
 template <class N>
@@ -217,6 +219,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
         cur = surv;
         cur.insert(cur.end(), kids.begin(), kids.end());
         steps += 1;
+        if (opts->max_beams > 0 && (int64_t)nodes.size() > (int64_t)opts->max_beams) throw BeamLimit{};  // bmo_trace_opts.max_beams, like the engine
     }
     // canonical order
     const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
@@ -472,6 +475,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
         cur = surv;
         cur.insert(cur.end(), kids.begin(), kids.end());
         steps += 1;
+        if (opts->max_beams > 0 && (int64_t)nodes.size() > (int64_t)opts->max_beams) throw BeamLimit{};  // bmo_trace_opts.max_beams, like the engine
     }
     const int64_t nn = (int64_t)nodes.size(), nr = (int64_t)all.size();
     std::vector<int> order(nn), rank(nn);
@@ -560,12 +564,17 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
 extern "C" {
 int bmo_emu_trace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, void** handle, bmo_trace_result_view* v) {
     auto* R = new ResultE();
-    if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v);
-    else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v);
-    else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v);
-    else {
+    try {
+        if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v);
+        else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v);
+        else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v);
+        else {
+            delete R;
+            return BMO_ERR_UNSUPPORTED;
+        }
+    } catch (const BeamLimit&) {
         delete R;
-        return BMO_ERR_UNSUPPORTED;
+        return BMO_ERR_LIMIT;
     }
     *handle = R;
     return BMO_OK;
@@ -575,12 +584,17 @@ int bmo_emu_retrace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_
                     bmo_trace_result_view* v) {
     if (!prev || prev->n_roots != in->n || prev->beam_kind != in->kind) return BMO_ERR_INVALID;
     auto* R = new ResultE();
-    if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v, prev);
-    else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v, prev);
-    else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v, prev);
-    else {
+    try {
+        if (in->kind == BMO_BEAM_RAY) run<BMO_BEAM_RAY>(d, in, opts, *R, v, prev);
+        else if (in->kind == BMO_BEAM_POLARIZED) run<BMO_BEAM_POLARIZED>(d, in, opts, *R, v, prev);
+        else if (in->kind == BMO_BEAM_GAUSSIAN) run_gauss(d, in, opts, *R, v, prev);
+        else {
+            delete R;
+            return BMO_ERR_UNSUPPORTED;
+        }
+    } catch (const BeamLimit&) {
         delete R;
-        return BMO_ERR_UNSUPPORTED;
+        return BMO_ERR_LIMIT;
     }
     *handle = R;
     return BMO_OK;

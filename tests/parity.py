@@ -12,7 +12,7 @@ EMU = os.path.join(ROOT, "tests", "emu", "libbmo_emu.so")
 _emu = None
 
 
-def emu_trace(scene, bundle, r_max=100, prev=None):
+def emu_trace(scene, bundle, r_max=100, prev=None, max_beams=0):
     """Host build of the engine's lane code (tests/emu) — test-only.  prev = TraceResult of the previous solve => retrace."""
     global _emu
     if _emu is None:
@@ -27,7 +27,7 @@ def emu_trace(scene, bundle, r_max=100, prev=None):
                                          C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
     batch, keep = bmo.make_batch(scene, bundle)
     o = abi.TraceOpts()
-    o.r_max, o.device, o.record_segments, o.max_beams = int(r_max), 0, 1, 0
+    o.r_max, o.device, o.record_segments, o.max_beams = int(r_max), 0, 1, int(max_beams)
     h = C.c_void_p()
     v = abi.ResultView()
     if prev is None:
@@ -35,6 +35,8 @@ def emu_trace(scene, bundle, r_max=100, prev=None):
     else:
         pv = prev.as_view()
         rc = _emu.bmo_emu_retrace(C.byref(scene.desc), C.byref(batch), C.byref(o), C.byref(pv), C.byref(h), C.byref(v))
+    if rc == -6:
+        raise RuntimeError("emulator: beam tree exceeds max_beams (-6)")
     assert rc == 0, rc
     try:
         return abi.TraceResult(v)
