@@ -45,30 +45,66 @@ def all_gather_hits(local_hits, group=None, async_op=False):
     return pending if async_op else pending.wait()
 
 
+class _GroupGather:
+    """One payload collective shared by the detectors of equal record width: every rank's block holds its hits of those detectors
+    back to back.  wait() -> per-rank blocks; PendingGather objects slice them."""
+
+    def __init__(self, work, outs):
+        self.work, self.outs = work, outs
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.outs
+
+
+class PendingGatherSlice(PendingGather):
+    """One detector's share of a _GroupGather: rows [start[r], start[r] + counts[r]) of every rank's block."""
+
+    def __init__(self, grp, starts, counts):
+        self.grp, self.starts, self.counts = grp, starts, counts
+
+    def wait(self):
+        outs = self.grp.wait()
+        hits = torch.cat([outs[r][int(self.starts[r]): int(self.starts[r]) + int(self.counts[r])] for r in range(len(outs))], dim=0)
+        return hits, self.counts
+
+
 def all_gather_hit_lists(payloads, group=None):
-    """The exchange step for several detectors at once: ONE collective for all their counts, then one payload all-gather per
-    detector left in flight.  payloads: list of [count_d, width_d] float64 tensors.  Returns a list of PendingGather."""
+    """The exchange step for several detectors at once: ONE collective for all their counts, then one payload all-gather per record
+    width (detectors of equal width share it) left in flight.  payloads: list of [count_d, width_d] float64 tensors.  Returns a
+    list of pending gathers, one per detector, whose wait() gives (hits [total, width] in reference order, counts [world])."""
     world = dist.get_world_size(group)
     dev = payloads[0].device
     cnt = torch.tensor([p.shape[0] for p in payloads], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(allc, cnt, group=group)
-    allc = torch.stack(allc).cpu()  # [world, nd]
-    out = []
-    for d, p in enumerate(payloads):
-        counts = allc[:, d].contiguous()
-        mx = max(int(counts.max()), 1)
-        width = p.shape[1]
+    allc = torch.stack(allc).cpu()  # [world, n_det]
+    out = [None] * len(payloads)
+    widths = sorted({p.shape[1] for p in payloads})
+    for width in widths:
+        members = [d for d, p in enumerate(payloads) if p.shape[1] == width]
+        tot = allc[:, members].sum(dim=1)  # rows of every rank's block
+        mx = max(int(tot.max()), 1)
         buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
-        buf[: p.shape[0]] = p
-        if dist.get_backend(group) == "nccl":
+        at = 0
+        for d in members:
+            n = payloads[d].shape[0]
+            buf[at: at + n] = payloads[d]
+            at += n
+        if dist.get_backend(group) == "nccl":  # one contiguous receive buffer: no per-rank copy kernels after the ring all-gather
             flat = torch.empty((world * mx, width), dtype=torch.float64, device=dev)
             work = dist.all_gather_into_tensor(flat, buf, group=group, async_op=True)
             outs = [flat[r * mx:(r + 1) * mx] for r in range(world)]
         else:
             outs = [torch.empty_like(buf) for _ in range(world)]
             work = dist.all_gather(outs, buf, group=group, async_op=True)
-        out.append(PendingGather(work, outs, counts))
+        grp = _GroupGather(work, outs)
+        starts = torch.zeros(world, dtype=torch.int64)
+        for d in members:
+            out[d] = PendingGatherSlice(grp, starts.clone(), allc[:, d].contiguous())
+            starts = starts + allc[:, d]
     return out
 
 

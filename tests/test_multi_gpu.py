@@ -138,3 +138,33 @@ def _lists_worker(rank, world, port, out_dir):
 def test_all_gather_hit_lists(tmp_path):
     mp.spawn(_lists_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _shared_width_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmo_amd import distributed as bd
+
+    # three detectors, two of them with the same width (they share one payload collective), ragged counts incl. empty
+    a = torch.arange((2 + rank) * 2, dtype=torch.float64).reshape(-1, 2) + 100 * rank
+    b = torch.arange((0 if rank == 0 else 4) * 2, dtype=torch.float64).reshape(-1, 2) + 1000 * rank + 7
+    c = torch.arange((1 + 2 * rank) * 9, dtype=torch.float64).reshape(-1, 9) + 5000 * rank
+    pend = bd.all_gather_hit_lists([a, c, b])
+    (ha, ca), (hc, cc), (hb, cb) = [p.wait() for p in pend]
+    ref_a = torch.cat([torch.arange(4, dtype=torch.float64).reshape(-1, 2), torch.arange(6, dtype=torch.float64).reshape(-1, 2) + 100])
+    ref_b = torch.arange(8, dtype=torch.float64).reshape(-1, 2) + 1007
+    ref_c = torch.cat([torch.arange(9, dtype=torch.float64).reshape(-1, 9), torch.arange(27, dtype=torch.float64).reshape(-1, 9) + 5000])
+    assert torch.equal(ha, ref_a) and ca.tolist() == [2, 3]
+    assert torch.equal(hb, ref_b) and cb.tolist() == [0, 4]
+    assert torch.equal(hc, ref_c) and cc.tolist() == [1, 3]
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_hit_lists_shared_width(tmp_path):
+    mp.spawn(_shared_width_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
