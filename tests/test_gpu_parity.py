@@ -273,3 +273,51 @@ def test_record_segments_off(engine_ok, oracle, kind):
         eng.free_batch(dev)
     finally:
         eng.close()
+
+
+def test_full_size_properties(engine_ok, oracle):
+    """BASELINE's full size (config C2, 2^20 rays; 19.9 M segments) through size-independent properties: determinism, the sharding
+    identity of SURVEY 8e (hit tables of contiguous shards concatenate to the un-sharded tables, bit for bit), the counters'
+    internal consistency, and a strided 1024-ray sample of the full solve against the oracle."""
+    n = 1 << 20
+    system, _ = c2_scene()
+    bundle = c2_bundle(n)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    eng = bmo.Engine(scene, 0)
+    try:
+        def solve(b, keep_log):
+            dev = eng.upload(b)
+            res = eng.trace_device(dev, 100, record_segments=keep_log)
+            size = eng.result_size(res)
+            v = eng.result_view(res)  # without the log this is the beam tree + hit tables only
+            eng.free_result(res)
+            eng.free_batch(dev)
+            return size, v
+
+        size_full, full = solve(bundle, False)
+        size_again, again = solve(bundle, True)  # the logging solve: same beams and hits, and its record count is checked below
+        assert size_full == size_again
+        calls, nrec, nnodes, nhits = size_full
+        assert nnodes == full.n_nodes == 3 * n and nhits == int(full.det_count.sum()) == 2 * n  # one splitter, both arms detected
+        assert int(full.node_nseg.astype(np.int64).sum()) == nrec == again.n_records
+        for name in ("node_root", "node_parent", "node_nseg", "node_status", "det_count", "det_node"):
+            assert np.array_equal(getattr(full, name), getattr(again, name)), name
+        assert np.array_equal(full.det_data, again.det_data)
+        # sharding identity
+        half = n // 2
+        parts = [solve(bmo.RayBundle(bundle.kind, bundle.planes[:, lo:lo + half]), False) for lo in (0, half)]
+        assert sum(p[0][0] for p in parts) == calls and sum(p[0][1] for p in parts) == nrec
+        for slot in range(len(scene.detectors)):
+            assert np.array_equal(np.concatenate([p[1].detector_hits(slot) for p in parts]), full.detector_hits(slot)), slot
+        # a strided sample against the oracle
+        idx = np.arange(0, n, 1024)
+        sample = bmo.RayBundle(bundle.kind, bundle.planes[:, idx])
+        ref = oracle.trace(scene, sample, 100, threads=16)
+        pick = np.isin(full.node_root, idx)
+        assert np.array_equal(full.node_nseg[pick], ref.node_nseg) and np.array_equal(full.node_status[pick], ref.node_status)
+        for slot in range(len(scene.detectors)):
+            lo, cnt = int(full.det_offset[slot]), int(full.det_count[slot])
+            roots_of_hits = full.node_root[full.det_node[lo:lo + cnt]]
+            assert np.array_equal(full.detector_hits(slot)[np.isin(roots_of_hits, idx)], ref.detector_hits(slot)), slot
+    finally:
+        eng.close()
