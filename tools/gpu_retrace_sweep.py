@@ -1,5 +1,5 @@
 """Wide randomised retrace sweep on the GPU box: random scene, solve, random small move of one element, retrace; engine vs oracle.
-usage: gpu_retrace_sweep.py [n_cases] [rays]"""
+usage: gpu_retrace_sweep.py [n_cases] [rays] [first seed]"""
 import os, resource, signal, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -11,8 +11,9 @@ from parity import compare
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+base = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 pyoracle.lib()
-cases = [(50000 + i, ("ray", "ray", "gauss", "pol")[i % 4]) for i in range(n_cases)]
+cases = [(base + i, ("ray", "ray", "gauss", "pol")[i % 4]) for i in range(n_cases)]
 t0 = time.time()
 bad, stale, runaway, big, done = [], 0, 0, 0, 0
 for i, (seed, kind) in enumerate(cases):
