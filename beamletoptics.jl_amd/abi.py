@@ -11,6 +11,8 @@ import numpy as np
 ABI_VERSION = 1
 NPARAM = 8
 
+VIEW_HITS, VIEW_LAST_SEGMENT, VIEW_SEGMENTS = 1, 2, 4  # bmo_result_view_select masks
+
 PLANES_IN = {0: 8, 1: 14, 2: 25}
 PLANES_REC = {0: 11, 1: 17, 2: 33}
 
@@ -101,6 +103,8 @@ class TraceResult:
         self.det_count = _np(v.det_count, nd, np.int64)
         self.det_offset = _np(v.det_offset, nd, np.int64)
         tot = int(self.det_count.sum())
+        if not v.det_data:  # a selective view without BMO_VIEW_HITS: counts only
+            tot = 0
         self.det_node = _np(v.det_node, tot, np.int32)
         self.det_data = _np(v.det_data, tot * 9, np.float64).reshape(tot, 9)
 
@@ -163,6 +167,8 @@ def load_engine():
     lib.bmo_result_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.bmo_result_counts.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.bmo_result_view.argtypes = [vp, C.POINTER(ResultView)]
+    lib.bmo_result_view_select.argtypes = [vp, C.c_uint32, C.POINTER(ResultView)]
+    lib.bmo_result_copy_hit_columns.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
     lib.bmo_result_free.argtypes = [vp]
     lib.bmo_retrace.argtypes = [vp, C.POINTER(RayBatch), vp, C.POINTER(TraceOpts), C.POINTER(vp)]
     lib.bmo_retrace_device.argtypes = [vp, vp, vp, C.POINTER(TraceOpts), C.POINTER(vp)]

@@ -861,6 +861,63 @@ __global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, 
     if (k % 9 == 0) out_node[pos + k / 9] = (int32_t)i;
 }
 
+// Node tables in the ABI's canonical order, built on the device (the host used to loop over 3 M nodes per C2 solve):
+//   rank[order[i]] = i, then for canonical node i (id nd = order[i]): root, parent's rank, nseg, status, aux; the transmitted child
+//   (path bit 0) writes itself as first_child of its parent — siblings are adjacent in BFS order, no atomics.
+__global__ void rank_kernel(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ rank) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rank[order[i]] = (int32_t)i;
+}
+__global__ void canon_nodes_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ rank, int64_t n, int gaussian, const int32_t* __restrict__ root,
+                                   const int32_t* __restrict__ parent, const int32_t* __restrict__ nseg, const int32_t* __restrict__ status,
+                                   const unsigned long long* __restrict__ key, const double* __restrict__ lambda, const double* __restrict__ aux,
+                                   int32_t* __restrict__ o_root, int32_t* __restrict__ o_parent, int32_t* __restrict__ o_first_child, int32_t* __restrict__ o_nseg,
+                                   int32_t* __restrict__ o_status, double* __restrict__ o_aux) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t nd = order[i];
+    const int32_t p = parent[nd];
+    o_root[i] = root[nd];
+    o_parent[i] = p < 0 ? -1 : rank[p];
+    o_nseg[i] = nseg[nd];
+    o_status[i] = status[nd];
+    if (gaussian) {
+        o_aux[4 * i + 0] = aux[4 * (int64_t)nd + 1];
+        o_aux[4 * i + 1] = aux[4 * (int64_t)nd + 2];
+        o_aux[4 * i + 2] = aux[4 * (int64_t)nd + 3];
+        o_aux[4 * i + 3] = lambda[nd];
+    } else {
+        o_aux[4 * i + 0] = lambda[nd];
+        o_aux[4 * i + 1] = o_aux[4 * i + 2] = o_aux[4 * i + 3] = 0.0;
+    }
+    if (p >= 0 && !(key[nd] & 1ull)) o_first_child[rank[p]] = (int32_t)i;
+}
+// dst_base[nd] = first record of node id nd in the node-major record order
+__global__ void dst_base_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ first_rec, int64_t n, int32_t* __restrict__ dst_base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst_base[order[i]] = first_rec[i];
+}
+// Last segment of every beam (last(rays(beam)), Beam.jl:79): record (node, k = nseg - 1) goes to column rank[node].
+__global__ void last_records_kernel(Chunk c, int planes, const int32_t* __restrict__ rank, const int32_t* __restrict__ nseg, int64_t nn, double* __restrict__ rec,
+                                    int32_t* __restrict__ obj, int32_t* __restrict__ shape) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c.count) return;
+    const int32_t nd = c.i[I_NODE * c.cap + j];
+    if (nd < 0) return;  // hole of a fused level
+    if (c.i[I_K * c.cap + j] != nseg[nd] - 1) return;
+    const int64_t dst = rank[nd];
+    for (int p = 0; p < planes; ++p) rec[(int64_t)p * nn + dst] = c.d[(int64_t)p * c.cap + j];
+    obj[dst] = c.i[I_OBJ * c.cap + j];
+    shape[dst] = c.i[I_SHAPE * c.cap + j];
+}
+// the leading n_cols columns of a [n][9] hit table, packed (a Spotdetector keeps x, y only: 16 of the 72 bytes)
+__global__ void hit_columns_kernel(const double* __restrict__ src, int64_t n, int n_cols, double* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cols) return;
+    const int64_t i = t / n_cols;
+    dst[t] = src[i * 9 + (t - i * n_cols)];
+}
+
 // Segment log -> the ABI's node-major order (bmo_trace_result_view.rec): record j of a step chunk goes to first_rec(node) + k.
 // Done in HBM so that the host receives ONE contiguous copy per table instead of re-ordering 10^7 records itself.
 __global__ void order_records_kernel(Chunk c, int planes, const int32_t* __restrict__ dst_base, int64_t nr, double* __restrict__ rec,
@@ -1021,7 +1078,9 @@ struct bmo_scene {
     std::vector<char> blob;
     BlobHeader hdr;
     std::vector<std::pair<int, std::unique_ptr<DevBuf>>> dev;  // per-device copy of the blob
+    std::mutex dev_mu;  // the handle is shared between host threads (include/bmo.h "Threading"): the lazy per-device upload is the one mutation
     const char* device_blob(int device, int& rc) {
+        std::lock_guard<std::mutex> lk(dev_mu);
         for (auto& d : dev)
             if (d.first == device) return static_cast<const char*>(d.second->p);
         auto b = std::make_unique<DevBuf>();
@@ -1065,11 +1124,12 @@ struct bmo_trace_result {
     bool rt_built = false;
     DevBuf rt_rec_start, rt_rec_obj, rt_first_child;
     std::vector<int64_t> det_count, det_offset;
-    // host views (filled by bmo_result_view)
-    bool viewed = false;
-    std::vector<int32_t> h_root, h_parent, h_first_child, h_first_rec, h_nseg, h_status;
-    std::vector<double> h_aux;
-    HostBuf h_rec, h_rec_obj, h_rec_shape, h_det, h_det_node;  // the large tables: pinned
+    // host views (filled by bmo_result_view / bmo_result_view_select), all page-locked; each part is materialised on first request
+    bool nodes_viewed = false, hits_viewed = false;
+    int rec_mode = 0;  // records on the host: 0 none, 1 last segment of every beam, 2 the whole log
+    HostBuf h_root, h_parent, h_first_child, h_first_rec, h_last_rec, h_nseg, h_status, h_aux;
+    HostBuf h_rec, h_rec_obj, h_rec_shape, h_det, h_det_node;
+    DevBuf c_rank, c_first_rec;  // canonical rank of every node id / first record of every canonical node (device, kept for record views)
 };
 
 namespace {
@@ -1332,6 +1392,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)BMO_CC_MAX * BMO_BLOCK * 8;  // + block_alloc scratch + child cache columns
     void (*kern)(StepParams) = nullptr;
     const bool asph = scene->hdr.has_asphere != 0;
+#if defined(BMO_DEV_RAY_LDS_ONLY)  // developer build (kernel work on one variant): everything else is refused, nothing falls back
+    if constexpr (KIND == BMO_BEAM_RAY) {
+        if (!prev && use_lds && !asph) kern = &step_kernel<BMO_BEAM_RAY, true, false, false>;
+    }
+    if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY, LDS> is compiled in");
+#else
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
         if (prev)
             kern = use_lds ? (asph ? &step_kernel_gauss<true, true, true> : &step_kernel_gauss<true, false, true>)
@@ -1347,6 +1413,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             kern = use_lds ? (asph ? &step_kernel<KIND, true, true, false> : &step_kernel<KIND, true, false, false>)
                            : (asph ? &step_kernel<KIND, false, true, false> : &step_kernel<KIND, false, false, false>);
     }
+#endif
     if (lds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
@@ -1816,9 +1883,10 @@ int bmo_result_device_hits(bmo_trace_result* r, int32_t det, const double** data
 }
 
 int bmo_result_copy_hits(bmo_trace_result* r, int32_t det, double* dst, int64_t max_hits) {
-    if (!r || det < 0 || det >= r->n_detectors || !dst) return fail(BMO_ERR_INVALID, "bad argument");
+    if (!r || det < 0 || det >= r->n_detectors) return fail(BMO_ERR_INVALID, "bad argument");
     const int64_t n = std::min<int64_t>(max_hits, r->det_count[det]);
-    if (n <= 0) return BMO_OK;
+    if (n <= 0) return BMO_OK;  // nothing to copy: an empty destination (NULL data pointer of a 0-row tensor) is fine
+    if (!dst) return fail(BMO_ERR_INVALID, "null destination");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemcpy(dst, static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det], (size_t)n * 72, hipMemcpyDefault));
     return BMO_OK;
@@ -1844,109 +1912,148 @@ int bmo_result_counts(bmo_trace_result* r, int64_t* calls, int64_t* records, int
     return BMO_OK;
 }
 
-int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) {
+int bmo_result_view_select(bmo_trace_result* r, uint32_t what, bmo_trace_result_view* v) {
     if (!r || !v) return fail(BMO_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->device));
-    if (!r->viewed) {
-        const int64_t nn = r->n_nodes, nr = r->n_records;
-        if (nr >= ((int64_t)1 << 31)) return fail(BMO_ERR_UNSUPPORTED, "result view: more than 2^31 segments (node_first_rec is 32-bit)");
-        std::vector<int32_t> root, parent, nseg, status, order;
-        std::vector<double> lambda;
-        int rc;
-        if ((rc = dl(root, r->n_root.p, nn)) || (rc = dl(parent, r->n_parent.p, nn)) || (rc = dl(nseg, r->n_nseg.p, nn)) ||
-            (rc = dl(status, r->n_status.p, nn)) || (rc = dl(order, r->order.p, nn)) || (rc = dl(lambda, r->n_lambda.p, nn)))
+    const int64_t nn = r->n_nodes, nr = r->n_records;
+    const int P = r->abi_planes;
+    int rc;
+    if (nr >= ((int64_t)1 << 31)) return fail(BMO_ERR_UNSUPPORTED, "result view: more than 2^31 segments (node_first_rec is 32-bit)");
+    const unsigned nb = (unsigned)((nn + 255) / 256);
+    if (!r->nodes_viewed) {
+        // canonical node tables on the device, one pinned copy each
+        const size_t n1 = (size_t)std::max<int64_t>(nn, 1);
+        DevBuf d_root, d_parent, d_fc, d_nseg, d_status, d_aux, d_last, tmp;
+        if ((rc = r->c_rank.alloc(n1 * 4)) || (rc = r->c_first_rec.alloc(n1 * 4)) || (rc = d_root.alloc(n1 * 4)) || (rc = d_parent.alloc(n1 * 4)) ||
+            (rc = d_fc.alloc(n1 * 4)) || (rc = d_nseg.alloc(n1 * 4)) || (rc = d_status.alloc(n1 * 4)) || (rc = d_aux.alloc(n1 * 32)) ||
+            (rc = r->h_root.alloc(n1 * 4)) || (rc = r->h_parent.alloc(n1 * 4)) || (rc = r->h_first_child.alloc(n1 * 4)) || (rc = r->h_first_rec.alloc(n1 * 4)) ||
+            (rc = r->h_last_rec.alloc(n1 * 4)) || (rc = r->h_nseg.alloc(n1 * 4)) || (rc = r->h_status.alloc(n1 * 4)) || (rc = r->h_aux.alloc(n1 * 32)))
             return rc;
-        std::vector<double> aux;
-        if (r->kind == BMO_BEAM_GAUSSIAN && (rc = dl(aux, r->n_aux.p, (size_t)nn * 4))) return rc;
-        std::vector<int32_t> rank(nn);
-        for (int64_t i = 0; i < nn; ++i) rank[order[i]] = (int32_t)i;
-        r->h_root.resize(nn);
-        r->h_parent.resize(nn);
-        r->h_first_child.assign(nn, -1);
-        r->h_first_rec.resize(nn);
-        r->h_nseg.resize(nn);
-        r->h_status.resize(nn);
-        r->h_aux.assign(nn * 4, 0.0);
-        int64_t acc = 0;
-        for (int64_t i = 0; i < nn; ++i) {
-            const int32_t nd = order[i];
-            r->h_root[i] = root[nd];
-            r->h_parent[i] = parent[nd] < 0 ? -1 : rank[parent[nd]];
-            r->h_nseg[i] = nseg[nd];
-            r->h_status[i] = status[nd];
-            r->h_first_rec[i] = (int32_t)acc;
-            if (r->kind == BMO_BEAM_GAUSSIAN) {
-                r->h_aux[4 * i + 0] = aux[4 * (size_t)nd + 1];
-                r->h_aux[4 * i + 1] = aux[4 * (size_t)nd + 2];
-                r->h_aux[4 * i + 2] = aux[4 * (size_t)nd + 3];
-                r->h_aux[4 * i + 3] = lambda[nd];
-            } else {
-                r->h_aux[4 * i] = lambda[nd];
-            }
-            acc += nseg[nd];
-        }
-        for (int64_t i = 0; i < nn; ++i) {
-            const int32_t p = r->h_parent[i];
-            if (p >= 0 && (r->h_first_child[p] < 0 || i < r->h_first_child[p])) r->h_first_child[p] = (int32_t)i;
-        }
-        if (acc != nr) return fail(BMO_ERR_INTERNAL, "segment count mismatch");
-        r->view_records = r->has_log ? nr : 0;
-        const int P = r->abi_planes;
-        int64_t tot = 0;
-        for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
-        const int64_t vr = r->view_records;
-        if ((rc = r->h_rec.alloc((size_t)P * vr * 8)) || (rc = r->h_rec_obj.alloc((size_t)vr * 4)) || (rc = r->h_rec_shape.alloc((size_t)vr * 4)) ||
-            (rc = r->h_det.alloc((size_t)tot * 72)) || (rc = r->h_det_node.alloc((size_t)tot * 4)))
-            return rc;
-        if (nr > 0 && r->has_log) {
-            // re-order on the device, then one copy per table
-            std::vector<int32_t> dst_base(nn);
-            for (int64_t i = 0; i < nn; ++i) dst_base[order[i]] = r->h_first_rec[i];
-            DevBuf d_base, d_rec, d_obj, d_shape;
-            if ((rc = d_base.alloc((size_t)nn * 4)) || (rc = d_rec.alloc((size_t)P * nr * 8)) || (rc = d_obj.alloc((size_t)nr * 4)) || (rc = d_shape.alloc((size_t)nr * 4)))
-                return rc;
-            HIP_TRY(hipMemcpy(d_base.p, dst_base.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemset(d_rec.p, 0, (size_t)P * nr * 8));
-            HIP_TRY(hipMemset(d_obj.p, 0xFF, (size_t)nr * 4));
-            HIP_TRY(hipMemset(d_shape.p, 0xFF, (size_t)nr * 4));
-            for (const Chunk& c : r->chunks)
-                if (c.count > 0)
-                    hipLaunchKernelGGL(order_records_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, 0, c, P, (const int32_t*)d_base.p, nr,
-                                       (double*)d_rec.p, (int32_t*)d_obj.p, (int32_t*)d_shape.p);
+        if (nn > 0) {
+            hipLaunchKernelGGL(rank_kernel, dim3(nb), dim3(256), 0, 0, (const int32_t*)r->order.p, nn, (int32_t*)r->c_rank.p);
+            HIP_TRY(hipMemsetAsync(d_fc.p, 0xFF, (size_t)nn * 4, 0));
+            hipLaunchKernelGGL(canon_nodes_kernel, dim3(nb), dim3(256), 0, 0, (const int32_t*)r->order.p, (const int32_t*)r->c_rank.p, nn,
+                               r->kind == BMO_BEAM_GAUSSIAN ? 1 : 0, (const int32_t*)r->n_root.p, (const int32_t*)r->n_parent.p, (const int32_t*)r->n_nseg.p,
+                               (const int32_t*)r->n_status.p, (const unsigned long long*)r->n_key.p, (const double*)r->n_lambda.p, (const double*)r->n_aux.p,
+                               (int32_t*)d_root.p, (int32_t*)d_parent.p, (int32_t*)d_fc.p, (int32_t*)d_nseg.p, (int32_t*)d_status.p, (double*)d_aux.p);
+            size_t tb = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const int32_t*)d_nseg.p, (int32_t*)r->c_first_rec.p, (int)nn, (hipStream_t)0));
+            if ((rc = tmp.alloc(tb))) return rc;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, (const int32_t*)d_nseg.p, (int32_t*)r->c_first_rec.p, (int)nn, (hipStream_t)0));
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpy(r->h_rec.p, d_rec.p, (size_t)P * nr * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_rec_obj.p, d_obj.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_rec_shape.p, d_shape.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(r->h_root.p, d_root.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_parent.p, d_parent.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_first_child.p, d_fc.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_first_rec.p, r->c_first_rec.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_nseg.p, d_nseg.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_status.p, d_status.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_aux.p, d_aux.p, (size_t)nn * 32, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipStreamSynchronize(0));
+            int32_t* lr = r->h_last_rec.as<int32_t>();  // LAST view: record i belongs to node i
+            for (int64_t i = 0; i < nn; ++i) lr[i] = (int32_t)i;
         }
+        r->nodes_viewed = true;
+    }
+    int64_t tot = 0;
+    for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
+    if ((what & BMO_VIEW_HITS) && !r->hits_viewed) {
+        if ((rc = r->h_det.alloc((size_t)tot * 72)) || (rc = r->h_det_node.alloc((size_t)tot * 4))) return rc;
         if (tot > 0) {
             HIP_TRY(hipMemcpy(r->h_det.p, r->det_data.p, (size_t)tot * 72, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(r->h_det_node.p, r->det_node.p, (size_t)tot * 4, hipMemcpyDeviceToHost));
         }
-        r->viewed = true;
+        r->hits_viewed = true;
     }
+    const int want_mode = !r->has_log ? 0 : ((what & BMO_VIEW_SEGMENTS) ? 2 : ((what & BMO_VIEW_LAST_SEGMENT) ? 1 : 0));
+    if (want_mode != 0 && want_mode != r->rec_mode && !(want_mode == 1 && r->rec_mode == 2)) {
+        const int64_t cols = want_mode == 2 ? nr : nn;  // records on the host
+        if ((rc = r->h_rec.alloc((size_t)P * cols * 8)) || (rc = r->h_rec_obj.alloc((size_t)cols * 4)) || (rc = r->h_rec_shape.alloc((size_t)cols * 4))) return rc;
+        if (cols > 0) {
+            // re-order on the device, then one copy per table
+            DevBuf d_base, d_rec, d_obj, d_shape;
+            if ((rc = d_rec.alloc((size_t)P * cols * 8)) || (rc = d_obj.alloc((size_t)cols * 4)) || (rc = d_shape.alloc((size_t)cols * 4))) return rc;
+            HIP_TRY(hipMemsetAsync(d_rec.p, 0, (size_t)P * cols * 8, 0));
+            HIP_TRY(hipMemsetAsync(d_obj.p, 0xFF, (size_t)cols * 4, 0));
+            HIP_TRY(hipMemsetAsync(d_shape.p, 0xFF, (size_t)cols * 4, 0));
+            if (want_mode == 2) {
+                if ((rc = d_base.alloc((size_t)nn * 4))) return rc;
+                hipLaunchKernelGGL(dst_base_kernel, dim3(nb), dim3(256), 0, 0, (const int32_t*)r->order.p, (const int32_t*)r->c_first_rec.p, nn, (int32_t*)d_base.p);
+            }
+            for (const Chunk& c : r->chunks) {
+                if (c.count <= 0) continue;
+                if (want_mode == 2)
+                    hipLaunchKernelGGL(order_records_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, 0, c, P, (const int32_t*)d_base.p, nr,
+                                       (double*)d_rec.p, (int32_t*)d_obj.p, (int32_t*)d_shape.p);
+                else
+                    hipLaunchKernelGGL(last_records_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, 0, c, P, (const int32_t*)r->c_rank.p,
+                                       (const int32_t*)r->n_nseg.p, nn, (double*)d_rec.p, (int32_t*)d_obj.p, (int32_t*)d_shape.p);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(r->h_rec.p, d_rec.p, (size_t)P * cols * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_rec_obj.p, d_obj.p, (size_t)cols * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_rec_shape.p, d_shape.p, (size_t)cols * 4, hipMemcpyDeviceToHost));
+        }
+        r->rec_mode = want_mode;
+    }
+    // what this view shows: the whole log only when asked for it (or when nothing narrower was asked and it is there)
+    const int show = (what & BMO_VIEW_SEGMENTS) ? (r->rec_mode == 2 ? 2 : 0) : ((what & BMO_VIEW_LAST_SEGMENT) ? (r->rec_mode == 1 ? 1 : 0) : 0);
+    if ((what & BMO_VIEW_LAST_SEGMENT) && !(what & BMO_VIEW_SEGMENTS) && r->rec_mode == 2)
+        return fail(BMO_ERR_INVALID, "result view: the whole log of this result is already on the host; ask for BMO_VIEW_SEGMENTS");
     std::memset(v, 0, sizeof *v);
     v->n_roots = r->n_roots;
     v->n_nodes = r->n_nodes;
-    v->n_records = r->view_records;  // 0 when the log was not kept (record_segments = 0); bmo_result_counts still reports the count
+    v->n_records = show == 2 ? nr : (show == 1 ? nn : 0);  // 0 when the log was not kept (record_segments = 0) or not asked for
     v->n_intersect_calls = (int64_t)r->calls;
     v->n_steps = r->n_steps;
     v->beam_kind = r->kind;
     v->rec_planes = r->abi_planes;
     v->n_detectors = r->n_detectors;
-    v->node_root = r->h_root.data();
-    v->node_parent = r->h_parent.data();
-    v->node_first_child = r->h_first_child.data();
-    v->node_first_rec = r->h_first_rec.data();
-    v->node_nseg = r->h_nseg.data();
-    v->node_status = r->h_status.data();
-    v->node_aux = r->h_aux.data();
-    v->rec_obj = r->h_rec_obj.as<int32_t>();
-    v->rec_shape = r->h_rec_shape.as<int32_t>();
-    v->rec = r->h_rec.as<double>();
+    v->node_root = r->h_root.as<int32_t>();
+    v->node_parent = r->h_parent.as<int32_t>();
+    v->node_first_child = r->h_first_child.as<int32_t>();
+    v->node_first_rec = show == 1 ? r->h_last_rec.as<int32_t>() : r->h_first_rec.as<int32_t>();
+    v->node_nseg = r->h_nseg.as<int32_t>();
+    v->node_status = r->h_status.as<int32_t>();
+    v->node_aux = r->h_aux.as<double>();
+    if (show) {
+        v->rec_obj = r->h_rec_obj.as<int32_t>();
+        v->rec_shape = r->h_rec_shape.as<int32_t>();
+        v->rec = r->h_rec.as<double>();
+    }
     v->det_count = r->det_count.data();
     v->det_offset = r->det_offset.data();
-    v->det_node = r->h_det_node.as<int32_t>();
-    v->det_data = r->h_det.as<double>();
+    if (what & BMO_VIEW_HITS) {
+        v->det_node = r->h_det_node.as<int32_t>();
+        v->det_data = r->h_det.as<double>();
+    }
+    return BMO_OK;
+}
+
+int bmo_result_view(bmo_trace_result* r, bmo_trace_result_view* v) { return bmo_result_view_select(r, BMO_VIEW_HITS | BMO_VIEW_SEGMENTS, v); }
+
+int bmo_result_copy_hit_columns(bmo_trace_result* r, int32_t det, int32_t n_cols, double* dst, int64_t max_hits) {
+    if (!r || det < 0 || det >= r->n_detectors || n_cols < 1 || n_cols > 9) return fail(BMO_ERR_INVALID, "bad argument");
+    const int64_t n = std::min<int64_t>(max_hits, r->det_count[det]);
+    if (n <= 0) return BMO_OK;
+    if (!dst) return fail(BMO_ERR_INVALID, "null destination");
+    HIP_TRY(hipSetDevice(r->device));
+    const double* src = static_cast<const double*>(r->det_data.p) + 9 * r->det_offset[det];
+    hipPointerAttribute_t at{};
+    const bool on_device = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // a pageable host pointer makes the query fail: not an error here
+    const unsigned grid = (unsigned)((n * n_cols + 255) / 256);
+    if (on_device) {
+        hipLaunchKernelGGL(hit_columns_kernel, dim3(grid), dim3(256), 0, 0, src, n, (int)n_cols, dst);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(0));
+        return BMO_OK;
+    }
+    DevBuf packed;
+    int rc = packed.alloc((size_t)n * n_cols * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(hit_columns_kernel, dim3(grid), dim3(256), 0, 0, src, n, (int)n_cols, (double*)packed.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(dst, packed.p, (size_t)n * n_cols * 8, hipMemcpyDeviceToHost));
     return BMO_OK;
 }
 

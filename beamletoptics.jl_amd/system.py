@@ -254,9 +254,13 @@ class Engine:
         abi.check(self.lib, self.lib.bmo_result_timing(res, C.byref(ms), C.byref(tot), C.byref(nl)), "bmo_result_timing")
         return ms.value, tot.value, nl.value
 
-    def result_view(self, res):
+    def result_view(self, res, what=None):
+        """bmo_result_view (the whole solution) or, with `what` (abi.VIEW_* mask), bmo_result_view_select."""
         v = abi.ResultView()
-        abi.check(self.lib, self.lib.bmo_result_view(res, C.byref(v)), "bmo_result_view")
+        if what is None:
+            abi.check(self.lib, self.lib.bmo_result_view(res, C.byref(v)), "bmo_result_view")
+        else:
+            abi.check(self.lib, self.lib.bmo_result_view_select(res, int(what), C.byref(v)), "bmo_result_view_select")
         return abi.TraceResult(v)
 
     def result_device_hits(self, res, slot):
@@ -267,6 +271,10 @@ class Engine:
 
     def result_copy_hits(self, res, slot, dst_device_ptr, max_hits):
         abi.check(self.lib, self.lib.bmo_result_copy_hits(res, slot, C.c_void_p(dst_device_ptr), max_hits), "bmo_result_copy_hits")
+
+    def result_copy_hit_columns(self, res, slot, n_cols, dst_ptr, max_hits):
+        """The leading n_cols columns of the ordered hit table of one detector, packed, into device or host memory."""
+        abi.check(self.lib, self.lib.bmo_result_copy_hit_columns(res, slot, int(n_cols), C.c_void_p(dst_ptr), max_hits), "bmo_result_copy_hit_columns")
 
     def result_counts(self, res):
         """Per-detector hit counts without downloading anything."""

@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on the HIP engine: ray-surface intersections/s (and rays/s).
+"""bench.py — BASELINE.json's metric on the HIP engine: ray-surface intersections/s (and rays/s, beamlets/s).
 
-A "step" = one full pass of the hot path over one batch: solve_system!(system, bundle) for 2^20 fresh
-geometric Rays through the 10-element mesh+SDF miniscope scene with one beamsplitter (BASELINE config
-"1M Rays, single MI355X, 10-element mesh+SDF system with one beamsplitter").  The bundle is uploaded
-once; the timed region runs bmo_trace_device K times (all bounce-step kernels, child spawning, node
-ordering, detector-hit compaction; results stay in HBM) and, for N > 1, the RCCL all-gather of the
-per-GPU detector hit buffers.
+A "step" = one full pass of the hot path over one batch: solve_system!(system, bundle) on fresh beams.  The bundle is uploaded
+once; the timed region runs bmo_trace_device K times (all bounce-step kernels, child spawning, node ordering, detector-hit
+compaction; results stay in HBM) and, for N > 1, the RCCL all-gather of the per-GPU detector hit buffers.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--workload c2|c2v|c3|c4|c5]
 
-N > 1 is launched by torch.distributed.run with one rank per GPU (weak scaling: every rank traces its own
-contiguous shard of R rays of one global Fibonacci bundle).  Rank 0 prints ONE JSON line.
+N = 1 (default): BASELINE config 2 — 2^20 geometric Rays through the 10-element mesh+SDF miniscope scene with one beamsplitter.
+                 The same line also carries the other BASELINE configs at their per-GPU sizes (`configs`), a vignetted C2
+                 bundle, the PCIe-inclusive rates of the host-buffer boundary (`pcie`) and the CPU baseline.
+N > 1:           BASELINE config 5 — the 32-element scene, 2^21 Rays per GPU (weak scaling: 2^24 at 8 GPUs), contiguous shards,
+                 RCCL all-gather of the detector hit lists.  Started either by the driver under torch.distributed.run, or as
+                 plain `python bench.py --gpus N`: the N ranks are then started as child processes (before this process touches
+                 a GPU) and rank 0's JSON line is relayed.
+Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,22 +28,154 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BYTES_PER_BOUNCE = 184  # 64+8 read, 40+64+8 written per bounce of a geometric Ray
-BYTES_PER_HIT = 16  # Spotdetector record (Point2{Float64})
+# SURVEY.md §8d algorithmic bytes per bounce (segment 64 + hint 8 read; intersection 40 + segment 64 + hint 8 written) by beam kind
+BYTES_PER_BOUNCE = {0: 184, 1: 280, 2: 584}
+KERNEL_NAME = {0: "step_kernel<RAY>", 1: "step_kernel<POLARIZED>", 2: "step_kernel_gauss"}
 
 
-def cpu_baseline(scene, bundle_fn, sample, r_max):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=0, help="root beams per GPU (0 = the BASELINE size of the workload)")
+    ap.add_argument("--workload", default="", help="c2 | c2v | c3 | c4 | c5 (default: c2 at N = 1, c5 at N > 1)")
+    ap.add_argument("--r-max", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="rays for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other configs and the PCIe-inclusive rates")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (nothing here has touched a GPU or
+    imported torch) under torch.distributed.run and relay rank 0's JSON line.  Never exec: the child's exit code is ours."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stderr.write(p.stdout)
+    return p.returncode if p.returncode != 0 or line is not None else 1
+
+
+# ------------------------------------------------------------------------------------------------------------ workloads
+def workload(name, n, rank=0):
+    """(system, bundle, description) of one BASELINE config; the bundle of rank r is the r-th contiguous shard of the global one."""
+    import scenes
+    from scenes import SEED
+
+    lg = "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n)
+    if name == "c2":
+        return scenes.c2_scene()[0], scenes.c2_bundle(n, seed=SEED + rank), (
+            f"BASELINE config 2: {lg} geometric Rays per GPU (0.3 mm object disc, 0.25 rad cone, seed {SEED} + rank) through the 10-element "
+            "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors")
+    if name == "c2v":
+        return scenes.c2_scene()[0], scenes.c2_vignetted_bundle(n, seed=SEED + rank), (
+            f"config 2 scene, vignetted bundle: {lg} geometric Rays per GPU, 2.0 mm object disc (0.87 x the first aperture) and 0.6 rad cone: 10 % of the rays miss the first lens, 45 % reach the splitter, the rest "
+            "are clipped at lens rims and rings or leave the train after 3-26 segments")
+    if name == "c3":
+        return scenes.c2_scene()[0], scenes.c3_bundle(n), (
+            f"BASELINE config 3: {lg} GaussianBeamlets (TEM00, w0 = 50 um; 3 rays each) per GPU, same 10-element scene")
+    if name == "c4":
+        return scenes.c4_scene()[0], scenes.c4_bundle(n), (
+            f"BASELINE config 4: {lg} PolarizedRays per GPU through three singlets (6 refracting surfaces) + end stop")
+    if name == "c5":
+        return scenes.c5_scene()[0], scenes.c5_bundle(n, seed=SEED + rank), (
+            f"BASELINE config 5: {lg} geometric Rays per GPU (contiguous shard of the global bundle, seed {SEED} + rank) through the "
+            "32-element scene (3 miniscope trains, fold mirrors, prisms, one ThinBeamsplitter, two Spotdetectors, two baffles)")
+    raise SystemExit(f"unknown workload {name!r}")
+
+
+DEFAULT_RAYS = {"c2": 1 << 20, "c2v": 1 << 20, "c3": 1 << 20, "c4": 1 << 18, "c5": 1 << 21}
+
+
+class Case:
+    """One compiled workload resident on one GPU."""
+
+    def __init__(self, bmo, name, n, device, rank=0):
+        self.bmo, self.name = bmo, name
+        self.system, self.bundle, self.text = workload(name, n, rank)
+        self.scene = bmo.CompiledScene(self.system, self.bundle.lambdas)
+        self.eng = bmo.Engine(self.scene, device)
+        self.dev_batch = self.eng.upload(self.bundle)
+        self.kind = self.bundle.kind
+        self.n_det = len(self.scene.detectors)
+        # bytes of one detector record as the reference stores it: Spotdetector Point2 (16 B), PSF hit (72 B); x3 rays for a beamlet
+        sub = 3 if self.kind == 2 else 1
+        self.det_cols = [2 if d.kind == bmo.components.O_SPOT else 9 for d in self.scene.detectors]
+        self.det_bytes = [8 * c * sub for c in self.det_cols]
+
+    def close(self):
+        self.eng.free_batch(self.dev_batch)
+        self.eng.close()
+
+    def solve(self, r_max):
+        res = self.eng.trace_device(self.dev_batch, r_max)
+        kms, tms, nl = self.eng.result_timing(res)
+        return res, kms, nl
+
+    def measure(self, r_max, steps, warmup):
+        """K resident solves: (seconds, kernel ms, launches, counters of one solve)."""
+        for _ in range(warmup):
+            res, _, _ = self.solve(r_max)
+            self.eng.free_result(res)
+        t0 = time.perf_counter()
+        kms_sum, nl_sum, last = 0.0, 0, None
+        for _ in range(steps):
+            if last is not None:
+                self.eng.free_result(last)
+            last, kms, nl = self.solve(r_max)
+            kms_sum += kms
+            nl_sum += nl
+        dt = time.perf_counter() - t0
+        calls, nrec, nnodes, hits = self.eng.result_size(last)
+        counts = self.eng.result_counts(last)
+        self.eng.free_result(last)
+        return dt, kms_sum, nl_sum, dict(calls=calls, segments=nrec, nodes=nnodes, hits=hits, det_counts=counts)
+
+    def algorithmic_bytes(self, c):
+        sub = 3 if self.kind == 2 else 1
+        return c["segments"] * BYTES_PER_BOUNCE[self.kind] + sum(n // sub * b for n, b in zip(c["det_counts"], self.det_bytes))
+
+
+def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=None):
+    alg = case.algorithmic_bytes(c)  # one solve on this rank
+    achieved = alg * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    per_step = max(launches // max(steps, 1), 1)
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+        "kernel": KERNEL_NAME[case.kind], "launches_per_step": per_step, "avg_launch_ms": kernel_ms / max(launches, 1),
+        "algorithmic_bytes_per_launch": alg / per_step,
+        "note": "path is FP64-VALU/latency bound (SURVEY.md §8d): algorithmic HBM bytes are %d B/bounce + the detector records; "
+                "see DESIGN.md §4 for the VALU-side accounting" % BYTES_PER_BOUNCE[case.kind],
+    }
+
+
+def cpu_baseline(case, sample, r_max):
     """Reference-algorithm CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import pyoracle
 
     threads = min(os.cpu_count() or 1, 32)
-    b = bundle_fn(sample)  # strided subsample of the benchmark bundle
+    g = case.bundle
+    idx = (np.arange(sample) * (g.n // sample)).astype(np.int64)  # strided subsample of the benchmark bundle
+    b = case.bmo.RayBundle(g.kind, g.planes[:, idx])
     t = time.perf_counter()
-    ref = pyoracle.trace(scene, b, r_max, threads=threads)
+    ref = pyoracle.trace(case.scene, b, r_max, threads=threads)
     dt = time.perf_counter() - t
     return {"value": ref.n_intersect_calls / dt, "unit": "intersections/s", "cores": threads, "kind": "port",
             "sample": f"every (N/{sample})-th ray of the same bundle, same scene ({ref.n_intersect_calls} reference intersect3d calls, {dt:.1f} s wall, "
@@ -47,24 +183,77 @@ def cpu_baseline(scene, bundle_fn, sample, r_max):
             "rays_per_s": sample / dt}
 
 
+def pcie_rates(case, r_max, calls):
+    """The host-buffer form of the boundary on the headline workload (never `value`): best of 3 per variant."""
+    import ctypes as C
+
+    import numpy as np
+
+    bmo, eng, scene = case.bmo, case.eng, case.scene
+    lib = eng.lib
+    abi = bmo.abi
+    batch, keep = bmo.make_batch(scene, case.bundle)
+    o = eng.opts(r_max)
+    hit_bufs = {}
+
+    def host_solve():
+        res = C.c_void_p()
+        abi.check(lib, lib.bmo_trace(eng.handle, C.byref(batch), C.byref(o), C.byref(res)), "bmo_trace")
+        return res
+
+    def with_h2d():
+        lib.bmo_result_free(host_solve())
+
+    def with_hits():
+        res = host_solve()
+        for s in range(case.n_det):
+            cnt = eng.result_device_hits(res, s)[1]
+            w = case.det_cols[s]
+            if s not in hit_bufs or hit_bufs[s].shape[0] < cnt:
+                hit_bufs[s] = np.zeros((max(cnt, 1), w))  # the caller's buffer, reused across solves
+            eng.result_copy_hit_columns(res, s, w, hit_bufs[s].ctypes.data, cnt)
+        lib.bmo_result_free(res)
+
+    def with_view(what):
+        def f():
+            res = host_solve()
+            v = abi.ResultView()
+            abi.check(lib, lib.bmo_result_view_select(res, what, C.byref(v)), "bmo_result_view_select")
+            lib.bmo_result_free(res)
+        return f
+
+    out = {}
+    for name, fn, reps in (("with_h2d", with_h2d, 3), ("with_hits_d2h", with_hits, 3),
+                           ("with_last_segment_view", with_view(abi.VIEW_HITS | abi.VIEW_LAST_SEGMENT), 3),
+                           ("with_full_view", with_view(abi.VIEW_HITS | abi.VIEW_SEGMENTS), 2)):
+        fn()  # warm-up: pinned pools, page faults
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out[name] = {"ms": best * 1e3, "intersections_per_s": calls / best}
+    out["what"] = {"with_h2d": "bmo_trace: host ray batch in, solution left in HBM",
+                   "with_hits_d2h": "+ every detector's hit table (the columns the detector keeps) copied to host memory",
+                   "with_last_segment_view": "+ bmo_result_view_select(HITS | LAST_SEGMENT): beam tree, last ray of every beam and hits on the host",
+                   "with_full_view": "+ bmo_result_view: the whole segment log on the host (PCIe-bound)"}
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=int, default=1 << 20, help="root rays per GPU")
-    ap.add_argument("--r-max", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="rays for the CPU baseline (0 = skip)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dist = None
-    torch = None
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = torch = None
+    backend = None
+    device_ord = 0
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -79,27 +268,17 @@ def main():
             dist.init_process_group(backend)
 
     import bmo_amd as bmo
-    from scenes import c2_bundle, c2_scene
 
     if world > 1:
         from bmo_amd import distributed as bd
 
-    system, _ = c2_scene()
-    n_local = args.rays
-    n_global = n_local * world
-
-    # Weak scaling: the global bundle is the concatenation, in rank order, of one complete C2 bundle per GPU (same disc and cone
-    # distribution, the cone directions drawn from seed + rank), so every rank traces the N = 1 workload and its contiguous shard
-    # keeps the reference's detector order.  Slicing ONE disc into rank-sized rings would give the ranks unequal work.
-    from scenes import SEED
-
-    bundle = c2_bundle(n_local, seed=SEED + rank)
-    scene = bmo.CompiledScene(system, bundle.lambdas)
-    eng = bmo.Engine(scene, device_ord if world > 1 else 0)
-    dev_batch = eng.upload(bundle)
-    n_det = len(scene.detectors)
-
-    det_width = [2 if d.kind == bmo.components.O_SPOT else 9 for d in scene.detectors]  # a Spotdetector stores (x, y) only
+    name = args.workload or ("c2" if world == 1 else "c5")
+    n_local = args.rays or DEFAULT_RAYS[name]
+    # Weak scaling: the global bundle is the concatenation, in rank order, of one complete bundle per GPU (same disc and cone
+    # distribution, directions drawn from seed + rank), so every rank traces the same amount of work and its contiguous shard keeps
+    # the reference's detector order.  Slicing ONE disc into rank-sized rings would give the ranks unequal work.
+    case = Case(bmo, name, n_local, device_ord, rank)
+    eng, n_det = case.eng, case.n_det
     in_flight = []  # exchange step of the previous trace, still travelling
 
     def finish_exchange():
@@ -107,25 +286,22 @@ def main():
         in_flight.clear()
         return out
 
-    def one_step():
-        res = eng.trace_device(dev_batch, args.r_max)
-        kms, tms, nl = eng.result_timing(res)
-        counts = [eng.result_device_hits(res, s)[1] for s in range(n_det)]
-        if world > 1:
+    def one_step(exchange):
+        res, kms, nl = case.solve(args.r_max)
+        if exchange:
             # Exchange step: all-gather of the detector hit lists over xGMI — counts first, then the payload
-            # (the columns the detector keeps), left in flight so that it overlaps the NEXT trace (separate RCCL stream);
-            # the previous step's exchange is completed first, and the last one inside the timed region (sync()).
+            # (only the columns the detector keeps: 16 B per Spotdetector hit), left in flight so that it overlaps the NEXT
+            # trace (separate RCCL stream); the previous step's exchange is completed first, the last one inside the timed region.
             finish_exchange()
             payloads = []
             for s in range(n_det):
-                local = torch.empty((counts[s], 9), dtype=torch.float64, device="cuda")
-                eng.result_copy_hits(res, s, local.data_ptr(), counts[s])
-                payload = local[:, : det_width[s]].contiguous()
-                payloads.append(payload if backend == "nccl" else payload.cpu())
+                cnt = eng.result_device_hits(res, s)[1]
+                local = torch.empty((cnt, case.det_cols[s]), dtype=torch.float64, device="cuda")
+                eng.result_copy_hit_columns(res, s, case.det_cols[s], local.data_ptr(), cnt)
+                payloads.append(local if backend == "nccl" else local.cpu())
             if payloads:
                 in_flight.extend(bd.all_gather_hit_lists(payloads))
-        stats = dict(kernel_ms=kms, total_ms=tms, launches=nl, hits=counts)
-        return res, stats
+        return res, kms, nl
 
     def sync():
         if world > 1:
@@ -133,21 +309,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    totals = None
+    # N > 1: this rank's rate WITHOUT the exchange step, same workload, measured before the timed region — the one-GPU reference
+    # point of the same config, so that scaling can be read against the same work (N = 1 of the driver's curve runs config 2).
+    local_only = None
+    if world > 1:
+        dt0, _, _, c0 = case.measure(args.r_max, max(2, min(args.steps, 3)), 1)
+        local_only = c0["calls"] * max(2, min(args.steps, 3)) / dt0
+
     for _ in range(args.warmup):
-        res, st = one_step()
+        res, _, _ = one_step(world > 1)
         eng.free_result(res)
     sync()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
-    launches = 0
-    last = None
+    kernel_ms, launches, last = 0.0, 0, None
     for _ in range(args.steps):
         if last is not None:
             eng.free_result(last)
-        last, st = one_step()
-        kernel_ms += st["kernel_ms"]
-        launches += st["launches"]
+        last, kms, nl = one_step(world > 1)
+        kernel_ms += kms
+        launches += nl
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -157,31 +337,29 @@ def main():
 
     # workload counters of ONE step (identical every step: the trace is deterministic)
     calls, nrec, nnodes, hits = eng.result_size(last)  # bmo_result_counts: nothing is downloaded
-    traced = int(nrec)  # every record is one tracing_step
+    det_counts = eng.result_counts(last)
     eng.free_result(last)
+    mine = dict(calls=calls, segments=nrec, nodes=nnodes, hits=hits, det_counts=det_counts)
     if world > 1:
-        agg = torch.tensor([calls, traced, hits, n_local], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        agg = torch.tensor([calls, nrec, hits, n_local, nnodes], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(agg)
-        calls_all, traced_all, hits_all, rays_all = (float(x) for x in agg.cpu())
+        calls_all, traced_all, hits_all, rays_all, nodes_all = (float(x) for x in agg.cpu())
     else:
-        calls_all, traced_all, hits_all, rays_all = float(calls), float(traced), float(hits), float(n_local)
+        calls_all, traced_all, hits_all, rays_all, nodes_all = float(calls), float(nrec), float(hits), float(n_local), float(nnodes)
 
     if rank == 0:
-        value = calls_all * args.steps / dt
-        alg_bytes_step = traced * BYTES_PER_BOUNCE + hits * BYTES_PER_HIT  # this rank, one step
-        avg_launch_ms = kernel_ms / max(launches, 1)
-        achieved = alg_bytes_step * args.steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this timed
         # process): bytes per launch, measured with the same command at the default workload; null for any other workload.
-        traffic, traffic_src = None, None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_c2_1M.json")
-        if os.path.exists(tp) and n_local == (1 << 20) and args.r_max == 100:
+        traffic = traffic_src = None
+        tp = os.path.join(ROOT, "profiles", "r02_traffic_c2_1M.json")
+        if os.path.exists(tp) and name == "c2" and n_local == (1 << 20) and args.r_max == 100:
             tj = json.load(open(tp))
             traffic = (tj["fetch_bytes"] + tj["write_bytes"]) / tj["launches"]
             traffic_src = tj["source"]
+        unit_name = "beamlets_per_s" if case.kind == 2 else "rays_per_s"
         out = {
             "metric": "ray-surface intersections/s",
-            "value": value,
+            "value": calls_all * args.steps / dt,
             "unit": "intersections/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -192,33 +370,41 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "rays_per_s": rays_all * args.steps / dt,
+            unit_name: rays_all * args.steps / dt,
             "config": {
-                "workload": "1M geometric Rays (2^20 per GPU, Fibonacci disc + 0.25 rad cone, seed 20251003 + rank) through the 10-element "
-                            "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors; r_max=100; full segment log kept",
-                "rays_per_gpu": n_local, "elements": scene.n_objects, "shapes": len(scene.shape_list),
-                "segments_per_step": int(traced_all), "beam_nodes": int(nnodes), "detector_hits": int(hits_all),
-                "intersect3d_calls_per_step": int(calls_all), "parallelism": f"ray-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all-gather of detector hits" if world > 1 else ""),
+                "workload": case.text + f"; r_max={args.r_max}; full segment log kept",
+                "name": name, "rays_per_gpu": n_local, "elements": case.scene.n_objects, "shapes": len(case.scene.shape_list),
+                "segments_per_step": int(traced_all), "beam_nodes": int(nodes_all), "detector_hits": int(hits_all),
+                "intersect3d_calls_per_step": int(calls_all),
+                "parallelism": f"ray-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all-gather of detector hits" if world > 1 else ""),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "kernel": "step_kernel<RAY>", "launches_per_step": launches // max(args.steps, 1), "avg_launch_ms": avg_launch_ms,
-                "algorithmic_bytes_per_launch": alg_bytes_step / max(launches // max(args.steps, 1), 1),
-                "note": "path is FP64-VALU/latency bound (SURVEY.md §8d): algorithmic HBM bytes are 184 B/bounce + 16 B/hit; "
-                        "see DESIGN.md for the VALU-side accounting",
-            },
+            "roofline": roofline_of(case, mine, kernel_ms, launches, args.steps, traffic, traffic_src),
         }
+        if local_only is not None:
+            out["one_gpu_same_workload"] = {"value": local_only, "unit": "intersections/s",
+                                            "what": "rank 0, same shard, solves only (no exchange step), measured before the timed region"}
+        if world == 1 and not args.no_extras:
+            out["pcie"] = pcie_rates(case, args.r_max, calls)
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
-            def strided(sample):
-                g = c2_bundle(n_local)
-                idx = (np.arange(sample) * (n_local // sample)).astype(np.int64)
-                return bmo.RayBundle(g.kind, g.planes[:, idx])
-
-            out["cpu_baseline"] = cpu_baseline(scene, strided, min(args.cpu_sample, n_local), args.r_max)
-        print(json.dumps(out))
-    eng.free_batch(dev_batch)
-    eng.close()
+            out["cpu_baseline"] = cpu_baseline(case, min(args.cpu_sample, n_local), args.r_max)
+    case.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the other BASELINE configs at their per-GPU sizes, and the vignetted C2 bundle: 3 resident solves each after 1 warm-up
+        cfgs = {}
+        for other in ("c2v", "c3", "c4", "c5"):
+            if other == name:
+                continue
+            oc = Case(bmo, other, DEFAULT_RAYS[other], device_ord)
+            odt, okms, onl, c = oc.measure(args.r_max, 3, 1)
+            rl = roofline_of(oc, c, okms, onl, 3)
+            cfgs[other] = {"workload": oc.text, "beams": oc.bundle.n, "ms": odt / 3 * 1e3, "kernel_ms": okms / 3, "launches": onl // 3,
+                           "intersections_per_s": c["calls"] * 3 / odt, ("beamlets_per_s" if oc.kind == 2 else "rays_per_s"): oc.bundle.n * 3 / odt,
+                           "segments": c["segments"], "beam_nodes": c["nodes"], "detector_hits": c["hits"],
+                           "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"]}
+            oc.close()
+        out["configs"] = cfgs
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

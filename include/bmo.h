@@ -303,8 +303,29 @@ int bmo_result_copy_hits(bmo_trace_result* res, int32_t detector, double* dst, i
 int bmo_result_timing(bmo_trace_result* res, double* step_kernel_ms, double* total_ms, int32_t* n_launches);
 /* Size of the solution without downloading it: reference intersect3d calls, segments, beams (tree nodes), detector hits. */
 int bmo_result_counts(bmo_trace_result* res, int64_t* n_intersect_calls, int64_t* n_records, int64_t* n_nodes, int64_t* n_hits);
-/* Materialise host views (downloads + canonical ordering of the segment log). */
+/* Materialise host views (downloads + canonical ordering of the segment log): the whole solution, i.e.
+ * bmo_result_view_select(res, BMO_VIEW_HITS | BMO_VIEW_SEGMENTS, view). */
 int bmo_result_view(bmo_trace_result* res, bmo_trace_result_view* view);
+/* Selective view: the wrapper that only needs what the reference's users usually read after solve_system! —
+ * last(rays(beam)) (src/Beam.jl:79), the beam tree (src/AbstractTypes/AbstractBeam.jl:48-78) and the detectors' data
+ * (Spotdetector.jl:27, PSFDetector.jl:57) — does not pay for the segment log (3.7 GB per solve of config C2 over PCIe).
+ * The node tables (node_*) are always filled.  `what` is a mask of:
+ *   BMO_VIEW_HITS          det_node / det_data (det_count / det_offset are always valid)
+ *   BMO_VIEW_LAST_SEGMENT  rec / rec_obj / rec_shape hold ONE record per beam, its last ray segment: n_records = n_nodes and
+ *                          node_first_rec[i] = i, while node_nseg[i] stays the beam's true length(rays(beam))
+ *   BMO_VIEW_SEGMENTS      the whole log (wins over BMO_VIEW_LAST_SEGMENT)
+ * Without a record flag n_records = 0 and rec* = NULL.  Every part is downloaded once per result and kept in page-locked
+ * host memory; asking for BMO_VIEW_SEGMENTS after BMO_VIEW_LAST_SEGMENT replaces the record tables (earlier views' rec*
+ * pointers die), asking for BMO_VIEW_LAST_SEGMENT alone after the whole log is BMO_ERR_INVALID (the log already has it).
+ * A view may be taken from another host thread while the next solve of another result runs: its kernels and copies go to
+ * the NULL stream, which does not synchronise with the library's (non-blocking) trace stream. */
+#define BMO_VIEW_HITS 1u
+#define BMO_VIEW_LAST_SEGMENT 2u
+#define BMO_VIEW_SEGMENTS 4u
+int bmo_result_view_select(bmo_trace_result* res, uint32_t what, bmo_trace_result_view* view);
+/* bmo_result_copy_hits for the leading n_cols (1..9) columns only, packed [hits][n_cols]: a Spotdetector keeps x, y
+ * (Spotdetector.jl:59), so the multi-GPU all-gather moves 16 B per hit instead of 72.  dst: device or host memory. */
+int bmo_result_copy_hit_columns(bmo_trace_result* res, int32_t detector, int32_t n_cols, double* dst, int64_t max_hits);
 int bmo_result_free(bmo_trace_result* res);
 
 /* ------------------------------------------------------------------------------------------------

@@ -119,6 +119,13 @@ def c2_bundle(n, lam=1.064e-6, seed=SEED):
     return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, lam=lam, e1=[1, 0, 0], cone=0.25, seed=seed)
 
 
+def c2_vignetted_bundle(n, lam=1.064e-6, seed=SEED, diameter=2.0 * mm, cone=0.6):
+    """The ragged counterpart of c2_bundle: an object disc and a cone wider than the miniscope accepts, so part
+    of the bundle misses the first aperture, is clipped at lens rims / mechanical rings or leaves the train between elements —
+    beams end after different bounce counts and not every root reaches the splitter."""
+    return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=diameter, lam=lam, e1=[1, 0, 0], cone=cone, seed=seed)
+
+
 # ------------------------------------------------------------------------------------ C4
 def c4_scene():
     """Three singlets (bi-convex, meniscus, plano-convex => 6 refracting surfaces) + IntersectableObject end stop."""
@@ -216,9 +223,9 @@ def c5_scene():
     return system, dict(bs=bs, det_t=det_t, det_r=det_r)
 
 
-def c5_bundle(n, lam=1.064e-6):
+def c5_bundle(n, lam=1.064e-6, seed=SEED):
     """Ray k feeds train k mod 3 (object plane of that train)."""
-    b = c2_bundle(n, lam)
+    b = c2_bundle(n, lam, seed=seed)
     P = b.planes.copy()
     P[0] += np.array(C5_X)[np.arange(n) % 3]
     return bmo.RayBundle(b.kind, P)

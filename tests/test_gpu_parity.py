@@ -329,3 +329,90 @@ def test_full_size_properties(engine_ok, oracle, kind):
                 assert mine.shape == theirs.shape and np.allclose(mine, theirs, rtol=1e-10, atol=0), slot
     finally:
         eng.close()
+
+
+def test_selective_views(engine_ok, oracle):
+    """bmo_result_view_select: node tables always; hits, the last segment of every beam (last(rays(beam)), Beam.jl:79) or the whole
+    log on request — each equal to the matching part of the full view, which equals the oracle."""
+    from bmo_amd import abi
+
+    system, _ = c2_scene()
+    for bundle in (c2_bundle(3000), c3_bundle(500)):
+        scene = bmo.CompiledScene(system, bundle.lambdas)
+        ref = oracle.trace(scene, bundle, 100, threads=8)
+        eng = bmo.Engine(scene, 0)
+        try:
+            dev = eng.upload(bundle)
+            res = eng.trace_device(dev, 100)
+            nodes = eng.result_view(res, 0)
+            assert nodes.n_records == 0 and nodes.rec.size == 0 and nodes.det_data.size == 0
+            assert np.array_equal(nodes.det_count, ref.det_count)
+            last = eng.result_view(res, abi.VIEW_HITS | abi.VIEW_LAST_SEGMENT)
+            assert last.n_records == last.n_nodes == ref.n_nodes
+            assert np.array_equal(last.node_first_rec, np.arange(ref.n_nodes))
+            full = eng.result_view(res, abi.VIEW_HITS | abi.VIEW_SEGMENTS)
+            compare(full, ref, 0.0 if bundle.kind == 0 else LIBM_RTOL, "full view after narrower ones")
+            for v in (nodes, last):
+                for name in ("node_root", "node_parent", "node_first_child", "node_nseg", "node_status", "det_count", "det_offset"):
+                    assert np.array_equal(getattr(v, name), getattr(full, name)), name
+                assert np.array_equal(v.node_aux, full.node_aux, equal_nan=True)
+            at = full.node_first_rec + full.node_nseg - 1
+            assert np.array_equal(last.rec, full.rec[:, at], equal_nan=True)
+            assert np.array_equal(last.rec_obj, full.rec_obj[at]) and np.array_equal(last.rec_shape, full.rec_shape[at])
+            assert np.array_equal(last.det_data, full.det_data) and np.array_equal(last.det_node, full.det_node)
+            import ctypes as C
+
+            v = abi.ResultView()  # the whole log is on the host now: a LAST-only request is refused, not silently re-shaped
+            assert eng.lib.bmo_result_view_select(res, abi.VIEW_LAST_SEGMENT, C.byref(v)) == -1
+            eng.free_result(res)
+            eng.free_batch(dev)
+        finally:
+            eng.close()
+
+
+def test_hit_columns_and_empty_copies(engine_ok, oracle):
+    """bmo_result_copy_hit_columns packs the leading columns into host or device memory; a detector without hits accepts a NULL
+    destination (torch.empty((0, 9)).data_ptr() == 0) in both copy calls."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    system, _ = c2_scene()
+    bundle = c2_bundle(2048)
+    bundle.planes[3:6, :] = np.array([[1.0], [0.0], [0.0]])  # every ray leaves sideways: no detector is reached
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    eng = bmo.Engine(scene, 0)
+    try:
+        res = eng.trace_device(eng.upload(bundle), 100)
+        for slot in range(len(scene.detectors)):
+            assert eng.result_device_hits(res, slot)[1] == 0
+            eng.result_copy_hits(res, slot, 0, 0)
+            eng.result_copy_hit_columns(res, slot, 2, 0, 0)
+        eng.free_result(res)
+    finally:
+        eng.close()
+    bundle = c2_bundle(2048)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    ref = oracle.trace(scene, bundle, 100, threads=8)
+    eng = bmo.Engine(scene, 0)
+    try:
+        res = eng.trace_device(eng.upload(bundle), 100)
+        for slot in range(len(scene.detectors)):
+            cnt = eng.result_device_hits(res, slot)[1]
+            want = ref.detector_hits(slot)
+            assert cnt == len(want) > 0
+            for cols in (2, 5, 9):
+                host = np.full((cnt + 1, cols), -3.0)
+                eng.result_copy_hit_columns(res, slot, cols, host.ctypes.data, cnt)
+                assert np.array_equal(host[:cnt], want[:, :cols]) and np.all(host[cnt] == -3.0)
+                dptr = C.c_void_p()
+                assert hip.hipMalloc(C.byref(dptr), C.c_size_t(cnt * cols * 8)) == 0
+                eng.result_copy_hit_columns(res, slot, cols, dptr.value, cnt)
+                back = np.zeros((cnt, cols))
+                assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), dptr, C.c_size_t(cnt * cols * 8), 2) == 0  # hipMemcpyDeviceToHost
+                hip.hipFree(dptr)
+                assert np.array_equal(back, want[:, :cols])
+        with pytest.raises(RuntimeError):
+            eng.result_copy_hit_columns(res, 0, 10, 0, 1)
+        eng.free_result(res)
+    finally:
+        eng.close()

@@ -1,0 +1,259 @@
+"""Leaves of SURVEY §8 rows a8 / a11 / a23 that no GPU test had touched (VERDICT r01 missing #1, #4): PolarizationFilter
+(Polarizers/PolarizationFilter.jl:31-48, JonesCalculus.jl:29-45), NonInteractableObject (NonInteractable.jl:19) and the
+stand-alone primitive SDFs — SphereSDF (SphericalLensSDF.jl:86-89), CutSphereSDF (PrimitiveSDF.jl:112-124), BoxSDF (:41-46),
+CylinderSDF (:71-76) — as refracting bodies.
+
+Every scene runs twice against the oracle: through the host build of the lane code (CPU) and through the C ABI on the GPU.
+Bar: ids / counts / tree bit-exact; FP64 planes bit-exact for geometric rays, 1e-10 where libm enters (polarized).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bmo_amd as bmo
+from parity import compare, emu_trace
+from scenes import disc_bundle, mm, polarized_bundle
+
+R_MAX = 30
+NODE_BLOCKED, NODE_ERR_ORTHO = 128, 256
+
+
+# ------------------------------------------------------------------------------------------------ PolarizationFilter
+def _polarizer_train(roll_deg, tilt_deg=0.0, cutoff=None, second_roll=None):
+    """filter (rolled about the beam axis, optionally tilted) [-> second filter] -> singlet -> Spotdetector-free end stop."""
+    objs = []
+    f1 = bmo.PolarizationFilter(20 * mm) if cutoff is None else bmo.PolarizationFilter(20 * mm, cutoff_strength=cutoff)
+    bmo.yrotate3d(f1, math.radians(roll_deg))
+    if tilt_deg:
+        bmo.xrotate3d(f1, math.radians(tilt_deg))
+        bmo.zrotate3d(f1, math.radians(0.4 * tilt_deg))
+    objs.append(f1)
+    if second_roll is not None:
+        f2 = bmo.PolarizationFilter(20 * mm)
+        bmo.yrotate3d(f2, math.radians(second_roll))
+        bmo.translate3d(f2, [0, 6 * mm, 0])
+        objs.append(f2)
+    lens = bmo.SphericalLens(40 * mm, -60 * mm, 4 * mm, 25.4 * mm, 1.6)
+    bmo.xrotate3d(lens, math.radians(2))
+    bmo.translate3d(lens, [0, 15 * mm, 0])
+    stop = bmo.IntersectableObject(bmo.QuadraticFlatMesh(40 * mm))
+    bmo.translate3d(stop, [0, 50 * mm, 0])
+    return bmo.System(objs + [lens, stop])
+
+
+def _pol_bundle(n, jitter=0.02):
+    return polarized_bundle(n, center=[0.3 * mm, -10 * mm, -0.2 * mm], direction=[0, 1, 0], diameter=10 * mm, jitter=jitter, e1=[1, 0, 0])
+
+
+POLARIZER_CASES = [dict(roll_deg=0.0), dict(roll_deg=30.0), dict(roll_deg=75.0, tilt_deg=20.0), dict(roll_deg=140.0, tilt_deg=-35.0),
+                   dict(roll_deg=10.0, second_roll=70.0), dict(roll_deg=45.0, tilt_deg=12.0, second_roll=-45.0)]
+
+
+def _check_polarizer(trace, oracle, kw, n):
+    system = _polarizer_train(**kw)
+    b = _pol_bundle(n)
+    scene = bmo.CompiledScene(system, b.lambdas)
+    ref = oracle.trace(scene, b, R_MAX, threads=8)
+    got = trace(scene, b)
+    compare(got, ref, 1e-10, "polarizer %s" % kw)
+    # the filter acted: every root has a second segment whose field is not stronger than the first (Malus), none is an error
+    roots = np.flatnonzero(ref.node_parent < 0)
+    first = ref.node_first_rec[roots]
+    ok = ref.node_nseg[roots] >= 2
+    e0 = np.sqrt((ref.rec[11:17, first[ok]] ** 2).sum(axis=0))
+    e1 = np.sqrt((ref.rec[11:17, first[ok] + 1] ** 2).sum(axis=0))
+    assert ok.sum() > 0.9 * len(roots) and np.all(e1 <= e0 * (1 + 1e-12))
+    assert not (ref.node_status & NODE_ERR_ORTHO).any()
+    return ref
+
+
+@pytest.mark.parametrize("kw", POLARIZER_CASES, ids=lambda k: "-".join("%s%g" % (a[0], v) for a, v in k.items()))
+def test_polarizer_lane_code(oracle, kw):
+    _check_polarizer(lambda sc, b: emu_trace(sc, b, R_MAX), oracle, kw, 96)
+
+
+def _engine(scene, bundle, r_max=R_MAX):
+    eng = bmo.Engine(scene, 0)
+    try:
+        return eng.trace(bundle, r_max)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", POLARIZER_CASES, ids=lambda k: "-".join("%s%g" % (a[0], v) for a, v in k.items()))
+def test_polarizer_engine(oracle, kw):
+    _check_polarizer(_engine, oracle, kw, 2048)
+
+
+def _malus(trace, oracle):
+    """runtests.jl:2469-2503 through a whole bundle: identical rays, the filter rolled in 10 degree steps => |E1|^2 = |E0|^2 cos^2."""
+    b = _pol_bundle(64, jitter=0.0)
+    e_in = b.planes[8:14:2, 0]  # real parts of E0 (imaginary parts are 0): linear at 45 deg in (x, z)
+    for th in range(0, 360, 10):
+        f = bmo.PolarizationFilter(20 * mm)
+        bmo.yrotate3d(f, math.radians(th))
+        scene = bmo.CompiledScene(bmo.System([f]), b.lambdas)
+        got = trace(scene, b)
+        ref = oracle.trace(scene, b, R_MAX, threads=2)
+        compare(got, ref, 1e-10, "malus %d" % th)
+        axis = f.orientation()[:, 0]
+        want = float(np.dot(e_in, axis)) ** 2
+        E1 = got.rec[11:17, got.node_first_rec[0] + 1]
+        assert abs((E1 ** 2).sum() - want) <= 1e-12 * max(1.0, want)
+
+
+def test_malus_lane_code(oracle):
+    _malus(lambda sc, b: emu_trace(sc, b, R_MAX), oracle)
+
+
+@pytest.mark.gpu
+def test_malus_engine(oracle):
+    _malus(_engine, oracle)
+
+
+def _blocked(trace, oracle):
+    """PolarizationFilter.jl:41-43: the ray is dropped when norm(E0') is approximately the cutoff.  With identical rays the
+    transmitted norm is one number; a filter whose cutoff_strength is that number blocks them all (status BLOCKED, no 2nd ray)."""
+    b = _pol_bundle(128, jitter=0.0)
+    open_scene = bmo.CompiledScene(_polarizer_train(30.0), b.lambdas)
+    ref = oracle.trace(open_scene, b, R_MAX, threads=4)
+    E1 = ref.rec[11:17, ref.node_first_rec[0] + 1]
+    nrm = math.sqrt((E1[0] ** 2 + E1[1] ** 2 + (E1[2] ** 2 + E1[3] ** 2)) + (E1[4] ** 2 + E1[5] ** 2))
+    shut = bmo.CompiledScene(_polarizer_train(30.0, cutoff=nrm), b.lambdas)
+    ref2 = oracle.trace(shut, b, R_MAX, threads=4)
+    assert (ref2.node_status & NODE_BLOCKED).all() and (ref2.node_nseg == 1).all()
+    compare(trace(shut, b), ref2, 1e-10, "blocked")
+
+
+def test_polarizer_blocks_lane_code(oracle):
+    _blocked(lambda sc, b: emu_trace(sc, b, R_MAX), oracle)
+
+
+@pytest.mark.gpu
+def test_polarizer_blocks_engine(oracle):
+    _blocked(_engine, oracle)
+
+
+# ------------------------------------------------------------------------------------------------ NonInteractableObject
+def _ghost_scene():
+    """A NonInteractableObject (cuboid mesh) and one holding an SDF sit IN the beam in front of a lens: intersect3d gives
+    `nothing` for them (NonInteractable.jl:19), rays pass as if they were not there, the call count still includes them."""
+    cube = bmo.CubeMesh(6 * mm)
+    bmo.translate3d(cube, [-3 * mm, -12 * mm, -3 * mm])
+    ghost_mesh = bmo.NonInteractableObject(cube)
+    ghost_sdf = bmo.NonInteractableObject(bmo.SphereSDF(4 * mm))
+    bmo.translate3d(ghost_sdf, [1 * mm, 9 * mm, 0])
+    lens = bmo.SphericalLens(50 * mm, -50 * mm, 5 * mm, 25.4 * mm, 1.5)
+    det = bmo.Spotdetector(30 * mm)
+    bmo.translate3d(det, [0, 40 * mm, 0])
+    return bmo.System([ghost_mesh, lens, ghost_sdf, det]), (ghost_mesh, ghost_sdf)
+
+
+def _check_ghost(trace, oracle, n):
+    system, ghosts = _ghost_scene()
+    b = disc_bundle(n, [0, -30 * mm, 0], [0, 1, 0], 8 * mm, jitter=0.01, e1=[1, 0, 0])
+    scene = bmo.CompiledScene(system, b.lambdas)
+    ref = oracle.trace(scene, b, R_MAX, threads=8)
+    compare(trace(scene, b), ref, 0.0, "noninteractable")
+    assert not np.isin(ref.rec_obj, [0, 2]).any()  # never hit
+    assert int(ref.det_count[0]) == n
+    # same scene without the ghosts: identical rays, 2 fewer reference calls per un-hinted tracing step
+    bare = bmo.CompiledScene(bmo.System([o for o in system.objects() if o not in ghosts]), b.lambdas)
+    ref0 = oracle.trace(bare, b, R_MAX, threads=8)
+    assert np.array_equal(ref0.rec, ref.rec) and ref0.n_intersect_calls < ref.n_intersect_calls
+
+
+def test_noninteractable_lane_code(oracle):
+    _check_ghost(lambda sc, b: emu_trace(sc, b, R_MAX), oracle, 128)
+
+
+@pytest.mark.gpu
+def test_noninteractable_engine(oracle):
+    _check_ghost(_engine, oracle, 4096)
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone primitive SDFs
+def _primitive(name):
+    if name == "sphere":  # ball lens
+        o = bmo.Lens(bmo.SphereSDF(4 * mm), lambda lam: 1.7)
+    elif name == "cutsphere":  # a spherical cap (the part above the cut): curved side towards the beam after the flip, slightly tilted
+        o = bmo.Lens(bmo.CutSphereSDF(9 * mm, 3 * mm), lambda lam: 1.5)
+        bmo.xrotate3d(o, math.radians(187))
+        bmo.zrotate3d(o, math.radians(5))
+    elif name == "box":  # glass block, tilted: refraction in, TIR or refraction out
+        o = bmo.Lens(bmo.BoxSDF(12 * mm, 6 * mm, 10 * mm), lambda lam: 1.52)
+        bmo.xrotate3d(o, math.radians(17))
+        bmo.zrotate3d(o, math.radians(-8))
+    elif name == "cylinder":  # rod lens, axis along y after construction: roll it across the beam
+        o = bmo.Lens(bmo.CylinderSDF(4 * mm, 6 * mm), lambda lam: 1.6)
+        bmo.zrotate3d(o, math.radians(80))
+    else:
+        raise ValueError(name)
+    bmo.translate3d(o, [0.2 * mm, 0, -0.1 * mm])
+    det = bmo.Spotdetector(80 * mm)
+    bmo.translate3d(det, [0, 60 * mm, 0])
+    side = bmo.Spotdetector(120 * mm)
+    bmo.xrotate3d(side, math.radians(90))
+    bmo.translate3d(side, [0, 10 * mm, -50 * mm])
+    return bmo.System([o, det, side])
+
+
+PRIMS = ["sphere", "cutsphere", "box", "cylinder"]
+
+
+def _check_primitive(trace, oracle, name, n):
+    system = _primitive(name)
+    b = disc_bundle(n, [0, -25 * mm, 0], [0, 1, 0], 7 * mm, cone=0.04, e1=[1, 0, 0])
+    scene = bmo.CompiledScene(system, b.lambdas)
+    ref = oracle.trace(scene, b, R_MAX, threads=8)
+    compare(trace(scene, b), ref, 0.0, name)
+    kinds = {scene.shape_list[s].kind for s in np.unique(ref.rec_shape) if s >= 0}
+    assert system.objects()[0].shape.kind in kinds            # the primitive was hit ...
+    assert (ref.node_nseg >= 3).sum() > 0.5 * n               # ... entered and left by most rays
+    assert int(ref.det_count.sum()) > 0.5 * n
+    # on a union-free leaf the scene has exactly one shape per object
+    assert len(scene.shape_list) == 3
+
+
+@pytest.mark.parametrize("name", PRIMS)
+def test_primitive_lane_code(oracle, name):
+    _check_primitive(lambda sc, b: emu_trace(sc, b, R_MAX), oracle, name, 192)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PRIMS)
+def test_primitive_engine(oracle, name):
+    _check_primitive(_engine, oracle, name, 4096)
+
+
+def _mixed_train():
+    """All four primitives, a polarizer-free NonInteractable ghost and a doublet in one train (hints hand over between them)."""
+    objs, y = [], 0.0
+    for name, gap in (("sphere", 14), ("box", 16), ("cylinder", 16), ("cutsphere", 18)):
+        o = _primitive(name).objects()[0]
+        bmo.translate3d(o, [0, y, 0])
+        objs.append(o)
+        y += gap * mm
+    ghost = bmo.NonInteractableObject(bmo.BoxSDF(30 * mm, 2 * mm, 30 * mm))
+    bmo.translate3d(ghost, [0, 22 * mm, 0])
+    objs.insert(2, ghost)
+    det = bmo.Spotdetector(200 * mm)
+    bmo.translate3d(det, [0, y + 30 * mm, 0])
+    return bmo.System(objs + [det])
+
+
+def test_mixed_primitives_lane_code(oracle):
+    b = disc_bundle(160, [0, -25 * mm, 0], [0, 1, 0], 5 * mm, cone=0.02, e1=[1, 0, 0])
+    scene = bmo.CompiledScene(_mixed_train(), b.lambdas)
+    compare(emu_trace(scene, b, R_MAX), oracle.trace(scene, b, R_MAX, threads=8), 0.0, "mixed primitives")
+
+
+@pytest.mark.gpu
+def test_mixed_primitives_engine(oracle):
+    b = disc_bundle(4096, [0, -25 * mm, 0], [0, 1, 0], 5 * mm, cone=0.02, e1=[1, 0, 0])
+    scene = bmo.CompiledScene(_mixed_train(), b.lambdas)
+    ref = oracle.trace(scene, b, R_MAX, threads=16)
+    compare(_engine(scene, b), ref, 0.0, "mixed primitives gpu")
+    assert len(np.unique(ref.rec_obj[ref.rec_obj >= 0])) >= 4

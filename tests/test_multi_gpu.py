@@ -168,3 +168,54 @@ def _shared_width_worker(rank, world, port, out_dir):
 def test_all_gather_hit_lists_shared_width(tmp_path):
     mp.spawn(_shared_width_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _engine_worker(rank, world, port, n, out_dir):
+    """The N > 1 path with the HIP engine itself: every rank shards with bmo_trace_device on the one GPU of the test box, packs the
+    columns its detectors keep (bmo_result_copy_hit_columns into torch memory) and all-gathers them (gloo here, RCCL in bench.py)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bmo_amd as bmo
+    from bmo_amd import distributed as bd
+    from scenes import c5_bundle, c5_scene
+
+    system, _ = c5_scene()
+    full = c5_bundle(n)
+    full.planes[3:6, : n // 4] = np.array([[1.0], [0.0], [0.0]])  # rank 0's first rays leave sideways: ragged hit counts
+    lo, hi = bd.shard_bounds(n, rank, world)
+    shard = bmo.RayBundle(full.kind, full.planes[:, lo:hi])
+    scene = bmo.CompiledScene(system, full.lambdas)
+    eng = bmo.Engine(scene, 0)
+    res = eng.trace_device(eng.upload(shard), 100)
+    payloads = []
+    for slot in range(len(scene.detectors)):
+        cnt = eng.result_device_hits(res, slot)[1]
+        local = torch.empty((cnt, 2), dtype=torch.float64, device="cuda")
+        eng.result_copy_hit_columns(res, slot, 2, local.data_ptr(), cnt)
+        payloads.append(local.cpu())
+    gathered = [p.wait()[0].numpy() for p in bd.all_gather_hit_lists(payloads)]
+    eng.free_result(res)
+    if rank == 0:
+        import pyoracle
+
+        whole = eng.trace(full, 100)
+        ref = pyoracle.trace(scene, full, 100, threads=8)
+        for slot in range(len(scene.detectors)):
+            assert np.array_equal(gathered[slot], whole.detector_hits(slot)[:, :2]), slot
+            assert np.array_equal(gathered[slot], ref.detector_hits(slot)[:, :2]), slot
+        assert sum(len(g) for g in gathered) > 0
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_engine_sharded_hits_equal_unsharded(tmp_path):
+    world = 2
+    mp.spawn(_engine_worker, args=(world, _free_port(), 3072, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
