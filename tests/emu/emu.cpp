@@ -6,6 +6,7 @@
 // product package never loads it (see beamletoptics.jl_amd/abi.py: the engine is libbmo_hip.so only).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -27,7 +28,6 @@ struct NodeE {
     int old = -1;  // node of the previous solution this beam re-walks (retrace), -1 = fresh
 };
 struct BeamLimit {};
-
 // reference order of the beam nodes: bundle order x breadth-first order of each root's tree (the two children of a splitting beam are
 // created consecutively, transmitted first).  Any tree depth.
 template <class N>
@@ -115,7 +115,24 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
         const size_t m0 = cur.size();
 #endif
         std::vector<Rec> surv, kids;
+#if defined(BMO_EMU_STATS)
+        std::vector<long> per_rec;  // leaf sdf evaluations of every record of this level (wave imbalance = max over 64 records vs mean)
+        per_rec.reserve(cur.size());
+#endif
         for (Rec& r : cur) {
+#if defined(BMO_EMU_STATS)
+            struct Tally {
+                std::vector<long>& v;
+                long at;
+                const Rec& r;
+                ~Tally() {
+                    v.push_back(g_emu_sdf_leaf - at);
+                    if (g_emu_sdf_leaf - at > 500)
+                        fprintf(stderr, "  straggler: %ld leaf evals, k %d pos %.6f %.6f %.6f dir %.6f %.6f %.6f hint %d/%d -> hit obj %d shape %d t %.6g\n", g_emu_sdf_leaf - at, r.k,
+                                r.ray.pos.x, r.ray.pos.y, r.ray.pos.z, r.ray.dir.x, r.ray.dir.y, r.ray.dir.z, r.hobj, r.hshape, r.X.obj, r.X.shape, r.X.t);
+                }
+            } tally{per_rec, g_emu_sdf_leaf, r};
+#endif
             StepOut o;
             o.outcome = OUT_MISS;
             o.status = 0;
@@ -215,6 +232,19 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
 #if defined(BMO_EMU_STATS)
         fprintf(stderr, "step %2d records %6zu  union sdf evals/record %7.2f  leaf sdf evals/record %7.2f  dual normals/record %5.2f  numeric fallbacks/record %5.2f\n",
                 steps, m0, double(g_emu_sdf_any - a0) / m0, double(g_emu_sdf_leaf - l0) / m0, double(g_emu_normal - n0) / m0, double(g_emu_normal_fd - f0) / m0);
+        {
+            long wave_max_sum = 0, mx = 0;
+            for (size_t w = 0; w < per_rec.size(); w += 64) {
+                long m = 0;
+                for (size_t q = w; q < std::min(per_rec.size(), w + 64); ++q) m = std::max(m, per_rec[q]);
+                wave_max_sum += m * 64;
+                mx = std::max(mx, m);
+            }
+            std::vector<long> srt = per_rec;
+            std::sort(srt.begin(), srt.end());
+            fprintf(stderr, "         leaf evals per record: p50 %ld  p90 %ld  p99 %ld  max %ld   lane utilisation if a wave waits for its slowest lane: %.1f %%\n",
+                    srt[srt.size() / 2], srt[srt.size() * 9 / 10], srt[srt.size() * 99 / 100], mx, 100.0 * double(g_emu_sdf_leaf - l0) / double(std::max(1L, wave_max_sum)));
+        }
 #endif
         cur = surv;
         cur.insert(cur.end(), kids.begin(), kids.end());

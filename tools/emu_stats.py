@@ -1,4 +1,5 @@
-"""SDF evaluations per record and bounce level on C2, counted by the host emulator built with -DBMO_EMU_STATS (CPU only)."""
+"""SDF evaluations per record and bounce level on C2 (or its vignetted bundle: `emu_stats.py N c2v`), counted by the host emulator built
+with -DBMO_EMU_STATS (CPU only)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,5 +12,6 @@ emu.bmo_emu_trace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch),
 emu.bmo_emu_free.argtypes = [C.c_void_p]
 parity._emu = emu
 system, _ = scenes.c2_scene()
-b = scenes.c2_bundle(int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+b = scenes.c2_vignetted_bundle(n) if len(sys.argv) > 2 and sys.argv[2] == "c2v" else scenes.c2_bundle(n)
 parity.emu_trace(bmo.CompiledScene(system, b.lambdas), b, 20)
