@@ -1,0 +1,627 @@
+# GPUSystem.jl — the BeamletOptics.jl side of the drop-in boundary (SURVEY.md §8b): a container type that sends
+# `solve_system!` to the MI355X engine (libbmo_hip.so, C ABI of include/bmo.h) through `ccall`.
+#
+# How to bind it: copy this file to `src/GPUSystem.jl` of BeamletOptics.jl, add `include("GPUSystem.jl")` after
+# `include("System.jl")` in `src/BeamletOptics.jl` and `export GPUSystem`.  Nothing else of the package changes: the precedent for
+# "swap the container to change the execution strategy" is `StaticSystem` (src/System.jl:38-45).
+#
+#     sys  = GPUSystem(System([lens, splitter, detector]))          # wraps any AbstractSystem
+#     solve_system!(sys, CollimatedSource(...))                     # src/System.jl:463-468, on the GPU
+#     solve_system!(sys, beam)                                      # src/System.jl:444-461 (a second call retraces, :188-255)
+#
+# What runs where: this file only flattens the scene (`Leaves` order, src/System.jl:21), packs the first rays into planes, calls the
+# library and rebuilds `Beam.rays` / `Intersection` / `children` / detector data from the result tables, which arrive in the
+# reference's own order (bundle order x the BFS order of solve_system!).  All tracing and read-out arithmetic is in the library.
+# Anything the engine does not model (a user-defined AbstractObject / AbstractShape / beam type, an `n(λ)` that throws) makes the
+# call fall back to the wrapped system — the result is then the reference's by construction.
+#
+# Julia is not installed in the image this engine was built in, so this file has never been executed; the same call sequence,
+# struct layouts and flattening rules are exercised through ctypes by beamletoptics.jl_amd/system.py (its Python twin, function by
+# function) and by every `-m gpu` test.  Struct sizes are asserted below against the values tests/test_abi.py pins, and
+# tests/test_julia_binding.py checks this file against include/bmo.h (constants, field order, every ccall'ed symbol and its arity).
+# The engine computes in Float64; beams of another element type are converted on the way in and come back as Float64 values.
+
+const LIBBMO = get(ENV, "BMO_ENGINE_LIB", "libbmo_hip")
+
+# ------------------------------------------------------------------------------------------------ C structs (include/bmo.h)
+const BMO_ABI_VERSION = Int32(1)
+const BMO_OK = Cint(0)
+const BMO_ERR_UNSUPPORTED = Cint(-4)
+
+# bmo_node_status bits
+const NODE_MISS, NODE_STOPPED, NODE_RMAX, NODE_SPLIT, NODE_DETECTED = 1, 2, 4, 8, 16
+const NODE_ERR_UNIT, NODE_GAUSS_DIVERGED, NODE_BLOCKED, NODE_ERR_ORTHO, NODE_RETRACE_STALE = 32, 64, 128, 256, 512
+
+# bmo_shape_kind
+const K_MESH, K_SPHERE, K_PLANO, K_CONVEX, K_CONCAVE, K_UNION, K_BOX, K_CYLINDER, K_CUTSPHERE, K_RING, K_PRISM, K_MENISCUS = Int32.(0:11)
+const K_ASPH_CONVEX, K_ASPH_CONCAVE, K_CYL_CONVEX, K_CYL_CONCAVE, K_ACYL_CONVEX, K_ACYL_CONCAVE = Int32.(13:18)
+const SHAPE_FLAG_INEXACT = Int32(1)
+# bmo_object_kind
+const O_MIRROR, O_REFRACTIVE, O_DOUBLET, O_THIN_BS, O_PLATE_BS, O_CUBE_BS, O_SPOT, O_PSF, O_INTERSECTABLE, O_NONINTERACTABLE, O_POLARIZER,
+      O_PHOTODETECTOR = Int32.(0:11)
+# bmo_beam_kind and the plane counts of bmo_ray_batch / bmo_trace_result_view
+const BEAM_RAY, BEAM_POLARIZED, BEAM_GAUSSIAN = Int32(0), Int32(1), Int32(2)
+const PLANES_IN = (8, 14, 25)
+const VIEW_HITS, VIEW_LAST_SEGMENT, VIEW_SEGMENTS = UInt32(1), UInt32(2), UInt32(4)
+
+struct BmoShape                                    # bmo_shape, 288 bytes
+    kind::Int32; child_begin::Int32; child_count::Int32; tri_begin::Int32; tri_count::Int32; flags::Int32
+    pos::NTuple{3, Float64}
+    dir::NTuple{9, Float64}                        # orientation(shape), ROW-major
+    tdir::NTuple{9, Float64}                       # transposed_orientation(shape), row-major
+    p::NTuple{8, Float64}
+    bs_center::NTuple{3, Float64}; bs_radius::Float64
+end
+struct BmoObject                                   # bmo_object, 200 bytes
+    kind::Int32; shape::NTuple{3, Int32}; medium::NTuple{2, Int32}; detector::Int32; reserved::Int32
+    reflectance::Float64; transmittance::Float64; cutoff::Float64
+    jones::NTuple{18, Float64}
+end
+struct BmoSceneDesc                                # bmo_scene_desc
+    abi_version::Int32; n_objects::Int32; n_shapes::Int32; n_children::Int32
+    n_tris::Int32; n_media::Int32; n_lambda::Int32; n_detectors::Int32
+    objects::Ptr{BmoObject}; shapes::Ptr{BmoShape}; children::Ptr{Int32}
+    tris::Ptr{Float64}; n_table::Ptr{Float64}; lambdas::Ptr{Float64}; coefs::Ptr{Float64}
+    eps_srf::Float64; eps_ray::Float64; eps_ins::Float64; mt_keps::Float64; mt_leps::Float64; grad_h::Float64
+    march_iters::Int32; n_coefs::Int32
+end
+struct BmoRayBatch
+    n::Int64; kind::Int32; n_planes::Int32; planes::Ptr{Float64}; lambda_idx::Ptr{Int32}
+end
+struct BmoTraceOpts
+    r_max::Int32; device::Int32; record_segments::Int32; max_beams::Int32
+end
+struct BmoResultView                               # bmo_trace_result_view
+    n_roots::Int64; n_nodes::Int64; n_records::Int64; n_intersect_calls::Int64
+    n_steps::Int32; beam_kind::Int32; rec_planes::Int32; n_detectors::Int32
+    node_root::Ptr{Int32}; node_parent::Ptr{Int32}; node_first_child::Ptr{Int32}; node_first_rec::Ptr{Int32}
+    node_nseg::Ptr{Int32}; node_status::Ptr{Int32}; node_aux::Ptr{Float64}
+    rec_obj::Ptr{Int32}; rec_shape::Ptr{Int32}; rec::Ptr{Float64}
+    det_count::Ptr{Int64}; det_offset::Ptr{Int64}; det_node::Ptr{Int32}; det_data::Ptr{Float64}
+end
+@assert sizeof(BmoShape) == 288 && sizeof(BmoObject) == 200 && sizeof(BmoSceneDesc) == 144 && sizeof(BmoTraceOpts) == 16
+
+# ------------------------------------------------------------------------------------------------ the container
+"""
+    GPUSystem(inner::AbstractSystem; device = 0, max_beams = 0)
+
+An [`AbstractSystem`](@ref) whose `solve_system!` runs on the MI355X engine.  `inner` stays the source of truth for
+`objects(system)` and is what unsupported cases fall back to.  `max_beams > 0` stops a solve whose beam tree outgrows it (a
+splitter facing a mirror; `solve_system!` itself recurses until memory runs out).
+"""
+mutable struct GPUSystem{S <: AbstractSystem} <: AbstractSystem
+    inner::S
+    device::Int32
+    max_beams::Int32
+    # beams (or the beam group) solved before => bmo_trace_result* kept resident in HBM so that the next solve can retrace it
+    solved::IdDict{Any, Ptr{Cvoid}}
+    function GPUSystem(inner::S; device::Integer = 0, max_beams::Integer = 0) where {S <: AbstractSystem}
+        sys = new{S}(inner, Int32(device), Int32(max_beams), IdDict{Any, Ptr{Cvoid}}())
+        finalizer(release!, sys)
+        return sys
+    end
+end
+objects(s::GPUSystem) = objects(s.inner)
+refractive_index(s::GPUSystem, λ::Real) = refractive_index(s.inner, λ)
+
+"Frees the solutions kept for retracing (device memory of the segment logs)."
+function release!(sys::GPUSystem)
+    for (_, h) in sys.solved
+        h != C_NULL && ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), h)
+    end
+    empty!(sys.solved)
+    return nothing
+end
+
+struct BmoUnsupported <: Exception
+    what::String
+end
+struct BmoError <: Exception
+    code::Int
+    msg::String
+end
+function check(rc::Cint)
+    rc == BMO_OK && return nothing
+    msg = unsafe_string(ccall((:bmo_last_error, LIBBMO), Cstring, ()))
+    rc == BMO_ERR_UNSUPPORTED && throw(BmoUnsupported(msg))
+    throw(BmoError(rc, msg))
+end
+
+# ------------------------------------------------------------------------------------------------ scene flattening
+# row-major NTuple{9} of a 3x3 (Julia matrices are column-major)
+rowmajor(M) = ntuple(i -> Float64(M[(i - 1) ÷ 3 + 1, (i - 1) % 3 + 1]), 9)
+tup3(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]))
+pad8(v...) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, 8)
+
+mutable struct SceneTables
+    shapes::Vector{BmoShape}
+    shape_refs::Vector{Any}                        # Julia shape of every shape id (Intersection.shape is rebuilt from it)
+    shape_ids::IdDict{Any, Int32}
+    bounds::Vector{Tuple{NTuple{3, Float64}, Float64}}   # uninflated world bounding sphere per shape id
+    children::Vector{Int32}
+    tris::Vector{Float64}
+    coefs::Vector{Float64}
+    media::Vector{Vector{Float64}}
+    media_ids::IdDict{Any, Int32}
+    objects::Vector{BmoObject}
+    detectors::Vector{Any}
+    lambdas::Vector{Float64}
+end
+SceneTables(λs) = SceneTables(BmoShape[], Any[], IdDict{Any, Int32}(), Tuple{NTuple{3, Float64}, Float64}[], Int32[], Float64[], Float64[],
+                              Vector{Float64}[], IdDict{Any, Int32}(), BmoObject[], Any[], λs)
+
+# miss-cull inflation of bounding spheres (DESIGN.md "miss cull"; beamletoptics.jl_amd/system.py _BS_REL, _BS_ABS)
+const BS_REL, BS_ABS = 1e-6, 1e-6
+
+# local-frame bounding sphere (centre, radius) of every SDF kind — the twin of `_local_bound` in beamletoptics.jl_amd/shapes.py
+local_bound(s::PlanoSurfaceSDF) = ((0.0, s.thickness / 2, 0.0), hypot(s.thickness / 2, s.diameter / 2))
+local_bound(s::SphereSDF) = ((0.0, 0.0, 0.0), Float64(s.radius))
+local_bound(s::ConcaveSphericalSurfaceSDF) = ((0.0, -s.sag / 2, 0.0), hypot(s.sag / 2, s.diameter / 2))
+local_bound(s::ConvexSphericalSurfaceSDF) = ((0.0, s.sag / 2, 0.0), hypot(s.sag / 2, s.diameter / 2))
+local_bound(s::BoxSDF) = ((0.0, 0.0, 0.0), Float64(norm(s.dimensions)))
+local_bound(s::CylinderSDF) = ((0.0, 0.0, 0.0), hypot(s.radius, s.height))
+local_bound(s::CutSphereSDF) = ((0.0, 0.0, 0.0), Float64(s.radius))
+local_bound(s::RingSDF) = ((0.0, 0.0, 0.0), hypot(s.inner_radius + s.hwidth, s.hthickness))
+local_bound(s::RightAnglePrismSDF) = ((0.0, 0.0, 0.0), Float64(norm(s.dimensions)))
+function local_bound(s::AbstractAsphericalSurfaceSDF)
+    edge = aspheric_equation(s.diameter / 2, 1 / s.radius, s.conic_constant, s.coefficients)
+    lo, hi = extrema((0.0, edge, s.max_sag[1]))
+    return ((0.0, (lo + hi) / 2, 0.0), hypot((hi - lo) / 2, s.diameter / 2))
+end
+function local_bound(s::ConvexCylinderSDF)   # extrusion along local x of a cut disk in (y, z)
+    hc = sqrt(s.radius^2 - (s.diameter / 2)^2)
+    return ((0.0, 0.0, (hc + s.radius) / 2), sqrt((s.height / 2)^2 + (s.diameter / 2)^2 + ((s.radius - hc) / 2)^2))
+end
+function local_bound(s::ConcaveCylinderSDF)
+    sg = sag(abs(s.radius), s.diameter)
+    return ((0.0, sg / 2 * sign(s.radius), 0.0), sqrt((s.height / 2)^2 + (sg / 2)^2 + (s.diameter / 2)^2))
+end
+function local_bound(s::AbstractAcylindricalSurfaceSDF)
+    edge = aspheric_equation(s.diameter / 2, 1 / s.radius, s.conic_constant, s.coefficients)
+    lo, hi = extrema((0.0, edge, s.max_sag[1]))
+    return ((0.0, (lo + hi) / 2, 0.0), sqrt(((hi - lo) / 2)^2 + (s.diameter / 2)^2 + (s.height / 2)^2))
+end
+function world_bound(s::AbstractSDF)
+    c, r = local_bound(s)
+    return (tup3(position(s) + orientation(s) * Point3{Float64}(c...)), Float64(r))
+end
+"Conservative sphere around spheres (the twin of `_enclose` in shapes.py)."
+function enclose(spheres)
+    c, r = collect(spheres[1][1]), spheres[1][2]
+    for (c2t, r2) in spheres[2:end]
+        c2 = collect(c2t)
+        d = norm(c2 - c)
+        d + r2 <= r && continue
+        if d + r <= r2
+            c, r = c2, r2
+            continue
+        end
+        nr = (d + r + r2) / 2
+        c = c + (c2 - c) * ((nr - r) / d)
+        r = nr
+    end
+    return (tup3(c), Float64(r))
+end
+
+# kind and parameter vector of every leaf SDF (include/bmo.h enum bmo_shape_kind lists the order of p[])
+leaf_record(s::SphereSDF) = (K_SPHERE, pad8(s.radius))
+leaf_record(s::PlanoSurfaceSDF) = (K_PLANO, pad8(s.thickness, s.diameter))
+leaf_record(s::ConvexSphericalSurfaceSDF) = (K_CONVEX, pad8(s.radius, s.diameter, s.sag, s.height))
+leaf_record(s::ConcaveSphericalSurfaceSDF) = (K_CONCAVE, pad8(s.radius, s.diameter, s.sag))
+leaf_record(s::BoxSDF) = (K_BOX, pad8(s.dimensions...))
+leaf_record(s::CylinderSDF) = (K_CYLINDER, pad8(s.radius, s.height))
+leaf_record(s::CutSphereSDF) = (K_CUTSPHERE, pad8(s.radius, s.height, s.w))
+leaf_record(s::RingSDF) = (K_RING, pad8(s.inner_radius, s.hwidth, s.hthickness))
+leaf_record(s::RightAnglePrismSDF) = (K_PRISM, pad8(s.dimensions...))
+leaf_record(s::ConvexAsphericalSurfaceSDF) = (K_ASPH_CONVEX, pad8(s.radius, s.conic_constant, s.diameter, s.max_sag[1]))
+leaf_record(s::ConcaveAsphericalSurfaceSDF) = (K_ASPH_CONCAVE, pad8(s.radius, s.conic_constant, s.diameter, s.max_sag[1]))
+leaf_record(s::ConvexCylinderSDF) = (K_CYL_CONVEX, pad8(s.radius, s.diameter, s.height))
+leaf_record(s::ConcaveCylinderSDF) = (K_CYL_CONCAVE, pad8(s.radius, s.diameter, s.height))
+leaf_record(s::AconvexCylinderSDF) = (K_ACYL_CONVEX, pad8(s.radius, s.diameter, s.height, s.conic_constant, s.max_sag[1]))
+leaf_record(s::AconcaveCylinderSDF) = (K_ACYL_CONCAVE, pad8(s.radius, s.diameter, s.height, s.conic_constant, s.max_sag[1]))
+leaf_record(s::AbstractShape) = throw(BmoUnsupported("shape type $(typeof(s))"))
+has_coefficients(s) = s isa AbstractAsphericalSurfaceSDF || s isa AbstractAcylindricalSurfaceSDF
+
+function push_shape!(tb::SceneTables, s, rec_fields, bound)
+    kind, child_begin, child_count, tri_begin, tri_count, flags, p = rec_fields
+    c, r = bound
+    dir = orientation(s)                           # SphereSDF: identity (SphericalLensSDF.jl:82-84)
+    tdir = s isa AbstractSDF ? transposed_orientation(s) : transpose(dir)   # the stored copy(dir') of AbstractSDF.jl:20-27
+    push!(tb.shapes, BmoShape(kind, child_begin, child_count, tri_begin, tri_count, flags, tup3(position(s)), rowmajor(dir), rowmajor(tdir), p,
+                              c, r * (1 + BS_REL) + BS_ABS))
+    push!(tb.shape_refs, s)
+    push!(tb.bounds, bound)
+    id = Int32(length(tb.shapes) - 1)
+    tb.shape_ids[s] = id
+    return id
+end
+
+"Adds `s` (and, for unions and meniscus lenses, its children) to the shape table; returns its 0-based shape id."
+function add_shape!(tb::SceneTables, s::AbstractShape)
+    haskey(tb.shape_ids, s) && return tb.shape_ids[s]
+    return _add_shape!(tb, s)
+end
+function _add_shape!(tb::SceneTables, m::Mesh)
+    V, F = vertices(m), faces(m)
+    tri_begin = Int32(length(tb.tris) ÷ 9)
+    for f in axes(F, 1), k in 1:3, x in 1:3     # 9 doubles per triangle: V1 V2 V3 in world space, as intersect3d reads them (Mesh.jl:252)
+        push!(tb.tris, V[F[f, k], x])
+    end
+    lo, hi = vec(minimum(V, dims = 1)), vec(maximum(V, dims = 1))
+    c = (lo + hi) / 2
+    r = maximum(norm(V[i, :] - c) for i in axes(V, 1))
+    return push_shape!(tb, m, (K_MESH, Int32(0), Int32(0), tri_begin, Int32(size(F, 1)), Int32(0), pad8()), (tup3(c), Float64(r)))
+end
+function _add_shape!(tb::SceneTables, u::UnionSDF)
+    ids = Int32[add_shape!(tb, c) for c in u.sdfs]   # children first, in tuple order (UnionSDF.jl:53-56 folds left to right)
+    any(tb.shapes[i + 1].kind in (K_UNION, K_MESH) for i in ids) && throw(BmoUnsupported("nested UnionSDF"))
+    child_begin = Int32(length(tb.children))
+    append!(tb.children, ids)
+    flags = any(tb.shapes[i + 1].flags & SHAPE_FLAG_INEXACT != 0 for i in ids) ? SHAPE_FLAG_INEXACT : Int32(0)
+    bound = enclose([tb.bounds[i + 1] for i in ids])
+    return push_shape!(tb, u, (K_UNION, child_begin, Int32(length(ids)), Int32(0), Int32(0), flags, pad8()), bound)
+end
+function _add_shape!(tb::SceneTables, ml::MeniscusLensSDF)
+    # children = {convex, cylinder, concave}; their pos / dir are expressed in the meniscus frame (MeniscusLensSDF.jl:42-46)
+    ids = Int32[add_shape!(tb, ml.convex), add_shape!(tb, ml.cylinder), add_shape!(tb, ml.concave)]
+    child_begin = Int32(length(tb.children))
+    append!(tb.children, ids)
+    flags = any(tb.shapes[i + 1].flags & SHAPE_FLAG_INEXACT != 0 for i in ids) ? SHAPE_FLAG_INEXACT : Int32(0)
+    c_local, r = enclose([tb.bounds[ids[1] + 1], tb.bounds[ids[2] + 1]])   # max(min(convex, cylinder), -concave) lies inside convex U cylinder
+    c = tup3(position(ml) + orientation(ml) * Point3{Float64}(c_local...))
+    return push_shape!(tb, ml, (K_MENISCUS, child_begin, Int32(3), Int32(0), Int32(0), flags, pad8()), (c, r))
+end
+function _add_shape!(tb::SceneTables, s::AbstractSDF)
+    kind, p = leaf_record(s)
+    child_begin, child_count, flags = Int32(0), Int32(0), Int32(0)
+    if has_coefficients(s)       # even aspheric coefficients live in the pooled `coefs` table; first-order distance estimate
+        child_begin, child_count, flags = Int32(length(tb.coefs)), Int32(length(s.coefficients)), SHAPE_FLAG_INEXACT
+        append!(tb.coefs, Float64.(s.coefficients))
+    end
+    return push_shape!(tb, s, (kind, child_begin, child_count, Int32(0), Int32(0), flags, p), world_bound(s))
+end
+_add_shape!(::SceneTables, s::AbstractShape) = throw(BmoUnsupported("shape type $(typeof(s))"))
+
+"Row of the n(λ) table for a refractive index functor, evaluated on the host (functors cannot cross a C ABI)."
+function medium!(tb::SceneTables, n)
+    haskey(tb.media_ids, n) && return tb.media_ids[n]
+    push!(tb.media, Float64[n(λ) for λ in tb.lambdas])   # a DiscreteRefractiveIndex KeyError surfaces here, before tracing
+    return tb.media_ids[n] = Int32(length(tb.media) - 1)
+end
+
+const NO3 = (Int32(-1), Int32(-1), Int32(-1))
+const NO_JONES = ntuple(_ -> 0.0, 18)
+bmo_object(kind; shape = NO3, medium = (Int32(-1), Int32(-1)), detector = Int32(-1), R = 0.0, T = 0.0, cutoff = 0.0, jones = NO_JONES) =
+    BmoObject(kind, shape, medium, detector, Int32(0), Float64(R), Float64(T), Float64(cutoff), jones)
+one_shape(id) = (id, Int32(-1), Int32(-1))
+function detector_slot!(tb, o)
+    push!(tb.detectors, o)
+    return Int32(length(tb.detectors) - 1)
+end
+
+# one bmo_object per leaf object (object ids = position in `Leaves` order)
+object_record(tb, o::AbstractReflectiveOptic) = bmo_object(O_MIRROR; shape = one_shape(add_shape!(tb, shape(o))))
+object_record(tb, o::Union{Lens, Prism}) =
+    bmo_object(O_REFRACTIVE; shape = one_shape(add_shape!(tb, shape(o))), medium = (medium!(tb, refractive_index(o)), Int32(-1)))
+object_record(tb, o::DoubletLens) =
+    bmo_object(O_DOUBLET; shape = (add_shape!(tb, shape(o.front)), add_shape!(tb, shape(o.back)), Int32(-1)),
+               medium = (medium!(tb, refractive_index(o.front)), medium!(tb, refractive_index(o.back))))
+object_record(tb, o::ThinBeamsplitter) =
+    bmo_object(O_THIN_BS; shape = one_shape(add_shape!(tb, shape(o))), R = reflectance(o), T = transmittance(o))
+object_record(tb, o::AbstractPlateBeamsplitter) =   # shape = {substrate, coating} (PlateBeamsplitter.jl:44)
+    bmo_object(O_PLATE_BS; shape = (add_shape!(tb, shape(substrate(o))), add_shape!(tb, shape(coating(o))), Int32(-1)),
+               medium = (medium!(tb, refractive_index(substrate(o))), Int32(-1)), R = reflectance(coating(o)), T = transmittance(coating(o)))
+object_record(tb, o::CubeBeamsplitter) =            # shape = {front, back, coating} (CubeBeamsplitter.jl:30)
+    bmo_object(O_CUBE_BS; shape = (add_shape!(tb, shape(o.front)), add_shape!(tb, shape(o.back)), add_shape!(tb, shape(o.coating))),
+               medium = (medium!(tb, refractive_index(o.front)), medium!(tb, refractive_index(o.back))),
+               R = reflectance(o.coating), T = transmittance(o.coating))
+object_record(tb, o::Spotdetector) = bmo_object(O_SPOT; shape = one_shape(add_shape!(tb, shape(o))), detector = detector_slot!(tb, o))
+object_record(tb, o::PSFDetector) = bmo_object(O_PSF; shape = one_shape(add_shape!(tb, shape(o))), detector = detector_slot!(tb, o))
+object_record(tb, o::Photodetector) = bmo_object(O_PHOTODETECTOR; shape = one_shape(add_shape!(tb, shape(o))), detector = detector_slot!(tb, o))
+object_record(tb, o::IntersectableObject) = bmo_object(O_INTERSECTABLE; shape = one_shape(add_shape!(tb, shape(o))))
+object_record(tb, o::NonInteractableObject) = bmo_object(O_NONINTERACTABLE; shape = one_shape(add_shape!(tb, shape(o))))
+function object_record(tb, o::PolarizationFilter)
+    J = o.JMat.data                                  # GlobalJonesBasis, 3x3 complex; row-major (re, im) pairs
+    jones = ntuple(i -> (z = ComplexF64(J[(i - 1) ÷ 6 + 1, ((i - 1) ÷ 2) % 3 + 1]); isodd(i) ? real(z) : imag(z)), 18)
+    return bmo_object(O_POLARIZER; shape = one_shape(add_shape!(tb, shape(o))), cutoff = o.cutoff, jones = jones)
+end
+object_record(tb, o::AbstractObject) = throw(BmoUnsupported("object type $(typeof(o))"))
+
+"Flat tables of `leaves` at the wavelengths `λs` (sorted, distinct) + the descriptor that points into them (keep `tb` alive)."
+function flatten_scene(leaves, λs::Vector{Float64})
+    tb = SceneTables(λs)
+    for o in leaves
+        push!(tb.objects, object_record(tb, o))
+    end
+    ntab = isempty(tb.media) ? ones(max(1, length(λs))) : reduce(vcat, tb.media)   # [n_media][n_lambda], row-major
+    return tb, ntab
+end
+"The descriptor over `tb`'s arrays; the counts are the true ones, empty tables get a one-element stand-in so that no pointer is NULL."
+function scene_desc(tb::SceneTables, ntab::Vector{Float64})
+    counts = (length(tb.children), length(tb.tris) ÷ 9, length(tb.coefs))
+    isempty(tb.children) && push!(tb.children, Int32(0))
+    isempty(tb.tris) && append!(tb.tris, zeros(9))
+    isempty(tb.coefs) && push!(tb.coefs, 0.0)
+    return BmoSceneDesc(BMO_ABI_VERSION, length(tb.objects), length(tb.shapes), counts[1], counts[2], length(tb.media), length(tb.lambdas),
+                        length(tb.detectors),
+                        pointer(tb.objects), pointer(tb.shapes), pointer(tb.children), pointer(tb.tris), pointer(ntab), pointer(tb.lambdas), pointer(tb.coefs),
+                        1e-9, 1e-10, 1.0, 1e-9, 1e-9, 1e-8,      # AbstractSDF.jl:1-3, Mesh.jl:203, AbstractSDF.jl:83
+                        1000, counts[3])                          # AbstractSDF.jl:105,135
+end
+
+# ------------------------------------------------------------------------------------------------ first rays -> planes
+beam_kind(::Beam{T, Ray{T}}) where {T} = BEAM_RAY
+beam_kind(::Beam{T, PolarizedRay{T}}) where {T} = BEAM_POLARIZED
+beam_kind(::GaussianBeamlet) = BEAM_GAUSSIAN
+beam_kind(b::AbstractBeam) = throw(BmoUnsupported("beam type $(typeof(b))"))
+head_wavelength(b::Beam) = wavelength(first(rays(b)))
+head_wavelength(g::GaussianBeamlet) = wavelength(g)
+
+"""
+SoA planes of the root heads (include/bmo.h bmo_ray_batch): the FIRST ray of every root beam, dir as stored (the Ray constructor
+normalised it, Rays.jl:32-42).  Returns (planes [n_planes*n], lambda_idx [n]).
+"""
+function pack_first_rays(roots::Vector, kind::Int32, λs::Vector{Float64})
+    n = length(roots)
+    np = PLANES_IN[kind + 1]
+    P = zeros(Float64, n * np)
+    li = Vector{Int32}(undef, n)
+    put!(plane, j, v) = (P[(plane - 1) * n + j] = v)
+    for (j, b) in enumerate(roots)
+        λ = head_wavelength(b)
+        li[j] = Int32(searchsortedfirst(λs, λ) - 1)
+        if kind == BEAM_GAUSSIAN
+            for (base, sub) in ((0, b.chief), (6, b.waist), (12, b.divergence))
+                r = first(rays(sub))
+                for x in 1:3
+                    put!(base + x, j, position(r)[x])
+                    put!(base + 3 + x, j, direction(r)[x])
+                end
+            end
+            put!(19, j, λ); put!(20, j, refractive_index(first(rays(b.chief)))); put!(21, j, beam_waist(b))
+            put!(22, j, real(electric_field(b))); put!(23, j, imag(electric_field(b)))
+        else
+            r = first(rays(b))
+            for x in 1:3
+                put!(x, j, position(r)[x])
+                put!(3 + x, j, direction(r)[x])
+            end
+            put!(7, j, λ); put!(8, j, refractive_index(r))
+            if kind == BEAM_POLARIZED
+                E = polarization(r)
+                for x in 1:3
+                    put!(8 + 2x - 1, j, real(E[x]))
+                    put!(8 + 2x, j, imag(E[x]))
+                end
+            end
+        end
+    end
+    return P, li
+end
+
+# ------------------------------------------------------------------------------------------------ result tables -> beams
+struct HostView                                   # Julia arrays over the library-owned tables (valid until bmo_result_free)
+    v::BmoResultView
+    root::Vector{Int32}; parent::Vector{Int32}; first_rec::Vector{Int32}; nseg::Vector{Int32}; status::Vector{Int32}
+    aux::Matrix{Float64}                          # [4, n_nodes]
+    rec_obj::Vector{Int32}; rec_shape::Vector{Int32}
+    rec::Matrix{Float64}                          # [n_records, rec_planes]: plane p is column p
+    det_count::Vector{Int64}; det_offset::Vector{Int64}
+    det::Matrix{Float64}                          # [9, total hits]
+end
+function HostView(v::BmoResultView)
+    nn, nr, nd = Int(v.n_nodes), Int(v.n_records), Int(v.n_detectors)
+    w(p, dims...) = prod(dims) == 0 ? Array{eltype(p)}(undef, dims...) : unsafe_wrap(Array, p, dims)
+    cnt = w(v.det_count, nd)
+    tot = Int(sum(cnt))
+    return HostView(v, w(v.node_root, nn), w(v.node_parent, nn), w(v.node_first_rec, nn), w(v.node_nseg, nn), w(v.node_status, nn),
+                    w(v.node_aux, 4, nn), w(v.rec_obj, nr), w(v.rec_shape, nr), w(v.rec, nr, Int(v.rec_planes)), cnt, w(v.det_offset, nd),
+                    w(v.det_data, 9, tot))
+end
+
+# ray k (1-based record index r) of one (sub-)beam; `base` = first plane of that ray inside the record (0, 11, 22)
+function make_ray(::Type{T}, hv::HostView, r::Int, base::Int, λ, leaves, shape_refs; E0 = nothing) where {T}
+    R = hv.rec
+    pos = Point3{T}(R[r, base + 1], R[r, base + 2], R[r, base + 3])
+    dir = Point3{T}(R[r, base + 4], R[r, base + 5], R[r, base + 6])
+    t = R[r, base + 8]
+    isect = nothing
+    if isfinite(t)                                 # t = +Inf <=> intersection === nothing
+        o, s = hv.rec_obj[r], hv.rec_shape[r]
+        isect = Intersection{T}(o >= 0 ? leaves[o + 1] : nothing, s >= 0 ? shape_refs[s + 1] : nothing, T(t),
+                                Point3{T}(R[r, base + 9], R[r, base + 10], R[r, base + 11]))
+    end
+    n = T(R[r, base + 7])
+    E0 === nothing && return Ray{T}(pos, dir, isect, T(λ), n)
+    return PolarizedRay{T}(pos, dir, isect, T(λ), n, E0)   # the inner constructor re-checks E0 ⟂ dir (PolarizedRays.jl:54-56)
+end
+
+"""
+Rebuilds the beam trees from the result tables.  Nodes arrive in reference order (bundle order x BFS order, parents before
+children, transmitted child before reflected child), so one forward pass links everything.  Root nodes are the caller's own beam
+objects (mutated in place, like `solve_system!` does); child beams are created here.
+"""
+function rebuild_beams!(roots::Vector, kind::Int32, hv::HostView, leaves, shape_refs)
+    nn = length(hv.root)
+    nodes = Vector{Any}(undef, nn)
+    for i in 1:nn
+        par = hv.parent[i]
+        f, n = Int(hv.first_rec[i]), Int(hv.nseg[i])
+        recs = (f + 1):(f + n)
+        if kind == BEAM_GAUSSIAN
+            w0, E0, λ = hv.aux[1, i], complex(hv.aux[2, i], hv.aux[3, i]), hv.aux[4, i]
+            T = typeof(λ)
+            sub(base) = Beam{T, Ray{T}}([make_ray(T, hv, r, base, λ, leaves, shape_refs) for r in recs], nothing, Vector{Beam{T, Ray{T}}}())
+            if par < 0
+                g = roots[hv.root[i] + 1]
+                g.chief.rays, g.waist.rays, g.divergence.rays = sub(0).rays, sub(11).rays, sub(22).rays
+                empty!(g.children)                  # children are re-attached below (retrace keeps their identity in the engine)
+            else
+                g = GaussianBeamlet(sub(0), sub(11), sub(22), T(λ), T(w0), Complex{T}(E0))
+                p = nodes[par + 1]
+                parent!(g, p)                       # also links chief.parent (Gaussian.jl:113-117)
+                push!(children(p), g)
+            end
+            nodes[i] = g
+        else
+            λ = hv.aux[1, i]
+            T = typeof(λ)
+            mk(r) = kind == BEAM_POLARIZED ?
+                    make_ray(T, hv, r, 0, λ, leaves, shape_refs;
+                             E0 = Point3{Complex{T}}(complex(hv.rec[r, 12], hv.rec[r, 13]), complex(hv.rec[r, 14], hv.rec[r, 15]), complex(hv.rec[r, 16], hv.rec[r, 17]))) :
+                    make_ray(T, hv, r, 0, λ, leaves, shape_refs)
+            if par < 0
+                b = roots[hv.root[i] + 1]
+                b.rays = [mk(r) for r in recs]
+                empty!(b.children)
+            else
+                p = nodes[par + 1]
+                b = typeof(p)([mk(r) for r in recs], nothing, typeof(p.children)())
+                parent!(b, p)
+                push!(children(p), b)
+            end
+            nodes[i] = b
+        end
+    end
+    return nodes
+end
+
+"Exceptions the reference throws while tracing come back as status bits: re-raise for the first offending beam."
+function raise_status(hv::HostView)
+    for i in eachindex(hv.status)
+        s = hv.status[i]
+        s & NODE_ERR_UNIT != 0 && throw(ArgumentError("dir and normal must have a unit length of 1"))             # OpticUtils.jl:33-35
+        s & NODE_ERR_ORTHO != 0 && throw(ErrorException("Ray dir. and E0 must be orthogonal."))                    # PolarizedRays.jl:54-56
+    end
+    return nothing
+end
+
+"Appends the detector records of this solve in the reference's push! order (detectors are not reset, as in the reference)."
+function push_detector_data!(tb::SceneTables, hv::HostView, res::Ptr{Cvoid})
+    for (slot0, det) in enumerate(tb.detectors)
+        cnt, off = Int(hv.det_count[slot0]), Int(hv.det_offset[slot0])
+        if det isa Spotdetector
+            T = typeof(det.hw)
+            for h in (off + 1):(off + cnt)
+                push!(det, Point2{T}(hv.det[1, h], hv.det[2, h]))                                                   # Spotdetector.jl:50-61
+            end
+        elseif det isa PSFDetector
+            T = eltype(vertices(shape(det)))
+            for h in (off + 1):(off + cnt)
+                D = view(hv.det, :, h)
+                push!(det, PSFData{T}(Point3{T}(D[1], D[2], D[3]), Point3{T}(D[4], D[5], D[6]), D[7], D[8], D[9]))  # PSFDetector.jl:77-89
+            end
+        elseif det isa Photodetector && cnt > 0
+            # Photodetector.jl:69-107: field[i, j] += electric_field(gauss, r, z) * sqrt(proj), evaluated on the GPU from the segment
+            # log still resident in `res`.  Julia's column-major field[i, j] is the ABI's element [i + nx*j].
+            pos = collect(Float64, position(det)); ori = collect(rowmajor(orientation(det)))
+            xs, ys = collect(Float64, det.x), collect(Float64, det.y)
+            F = det.field isa Matrix{ComplexF64} ? det.field : ComplexF64.(det.field)
+            GC.@preserve pos ori xs ys F check(ccall((:bmo_photodetector_field, LIBBMO), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ptr{ComplexF64}, Ptr{Float64}),
+                res, slot0 - 1, pos, ori, xs, ys, length(xs), length(ys), F, C_NULL))
+            F === det.field || (det.field .= F)
+        end
+    end
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------------ solve_system!
+"""
+    solve_system!(system::GPUSystem, bg::AbstractBeamGroup; r_max = 100, retrace = true)
+    solve_system!(system::GPUSystem, beam::AbstractBeam;    r_max = 100, retrace = true)
+
+src/System.jl:444-468 on the GPU.  Fresh beams are traced (`bmo_trace`); beams this system solved before are retraced
+(`bmo_retrace`, src/System.jl:188-255 and :326-428) against the solution kept in HBM.  `retrace = false` on solved beams only
+re-traces leaves whose last ray has no intersection (src/System.jl:470-475); that rare mode is left to the wrapped system.
+"""
+function solve_system!(sys::GPUSystem, bg::AbstractBeamGroup; r_max::Int = 100, retrace::Bool = true)
+    return gpu_solve!(sys, bg, collect(beams(bg)); r_max, retrace)
+end
+function solve_system!(sys::GPUSystem, beam::AbstractBeam; r_max::Int = 100, retrace::Bool = true)
+    return gpu_solve!(sys, beam, Any[beam]; r_max, retrace)
+end
+
+function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Bool)
+    isempty(roots) && return nothing
+    prev = get(sys.solved, key, C_NULL)
+    fallback() = (forget!(sys, key); solve_system!(sys.inner, key; r_max, retrace))
+    prev != C_NULL && !retrace && return fallback()
+    local tb, ntab, kind
+    try
+        kind = beam_kind(first(roots))
+        all(b -> beam_kind(b) == kind, roots) || throw(BmoUnsupported("mixed beam kinds in one group"))
+        λs = sort(unique(Float64[head_wavelength(b) for b in roots]))
+        leaves = collect(objects(sys.inner))                                     # Leaves order = object ids (System.jl:21)
+        tb, ntab = flatten_scene(leaves, λs)
+        planes, li = pack_first_rays(roots, kind, λs)
+        scene, res, view = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL), Ref{BmoResultView}()
+        GC.@preserve tb ntab planes li begin
+            desc = scene_desc(tb, ntab)
+            check(ccall((:bmo_scene_create, LIBBMO), Cint, (Ref{BmoSceneDesc}, Ref{Ptr{Cvoid}}), desc, scene))
+            try
+                batch = BmoRayBatch(length(roots), kind, PLANES_IN[kind + 1], pointer(planes), pointer(li))
+                opts = BmoTraceOpts(r_max, sys.device, 1, sys.max_beams)
+                if prev == C_NULL   # fresh beams: retrace_system! is a no-op on them (System.jl:197-206)
+                    check(ccall((:bmo_trace, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoRayBatch}, Ref{BmoTraceOpts}, Ref{Ptr{Cvoid}}), scene[], batch, opts, res))
+                else                # the batch supplies the current root heads: edits of the first ray / E0 / w0 are honoured
+                    check(ccall((:bmo_retrace, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoRayBatch}, Ptr{Cvoid}, Ref{BmoTraceOpts}, Ref{Ptr{Cvoid}}),
+                                scene[], batch, prev, opts, res))
+                end
+            finally
+                ccall((:bmo_scene_destroy, LIBBMO), Cint, (Ptr{Cvoid},), scene[])
+            end
+        end
+        check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+        hv = HostView(view[])
+        if any(s -> s & NODE_RETRACE_STALE != 0, hv.status)
+            # the one place the engine deviates from retrace_system! (DESIGN.md §6 f1): let the reference handle this solve
+            ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
+            return fallback()
+        end
+        try
+            raise_status(hv)
+            rebuild_beams!(roots, kind, hv, leaves, tb.shape_refs)
+            push_detector_data!(tb, hv, res[])
+        catch
+            ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
+            forget!(sys, key)
+            rethrow()
+        end
+        forget!(sys, key)
+        sys.solved[key] = res[]        # stays in HBM for the next (re)trace; freed by forget! / release! / the finalizer
+    catch e
+        e isa BmoUnsupported || rethrow()
+        return fallback()
+    end
+    return nothing
+end
+function forget!(sys::GPUSystem, key)
+    h = pop!(sys.solved, key, C_NULL)
+    h != C_NULL && ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), h)
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------------ detector read-out on the GPU
+"""
+    gpu_intensity(psf::PSFDetector; n = 100, crop_factor = 1, x0_shift = 0, z0_shift = 0, device = 0)
+
+`intensity(psf)` (PSFDetector.jl:190-237) with the n² x hits coherent sum evaluated by `bmo_psf_intensity`; the sample grid is
+computed exactly as the reference does (`calc_local_lims`, two `LinRange`s).  Returns `(xs, zs, I)` like the reference.
+"""
+function gpu_intensity(psf::PSFDetector{T}; n::Int = 100, crop_factor::Real = 1, center::Symbol = :centroid, x_min = Inf, x_max = Inf, z_min = Inf,
+                       z_max = Inf, x0_shift::Real = 0, z0_shift::Real = 0, device::Integer = 0) where {T}
+    _x_min, _x_max, _z_min, _z_max = calc_local_lims(psf; crop_factor = crop_factor, center = center)
+    (x_min != Inf && x_max != Inf) && ((_x_min, _x_max) = (x_min, x_max))
+    (z_min != Inf && z_max != Inf) && ((_z_min, _z_max) = (z_min, z_max))
+    xs = collect(Float64, LinRange(_x_min, _x_max, n) .+ x0_shift)
+    zs = collect(Float64, LinRange(_z_min, _z_max, n) .+ z0_shift)
+    hits = reinterpret(Float64, psf.data)                                      # 9 doubles per PSFData: hit, dir, opl, proj, k
+    R = orientation(psf)
+    origin, e1, e2 = collect(Float64, position(psf)), collect(Float64, R[:, 1]), collect(Float64, R[:, 3])
+    I = Matrix{Float64}(undef, n, n)
+    GC.@preserve hits xs zs origin e1 e2 I check(ccall((:bmo_psf_intensity, LIBBMO), Cint,
+        (Ptr{Float64}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        pointer(hits), length(psf.data), 0, origin, e1, e2, xs, zs, n, device, I, C_NULL, C_NULL))
+    return xs, zs, I
+end

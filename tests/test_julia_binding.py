@@ -1,0 +1,165 @@
+"""julia/GPUSystem.jl cannot be executed in this image (no Julia toolchain), so it is checked statically against the contract it binds:
+include/bmo.h (symbols, arities, enum values) and the ctypes mirrors of beamletoptics.jl_amd/abi.py that every GPU test goes through
+(struct field order and types).  A drift of the header that is not followed in the Julia file fails here."""
+import ctypes as C
+import os
+import re
+
+import bmo_amd as bmo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = open(os.path.join(ROOT, "julia", "GPUSystem.jl")).read()
+HDR = open(os.path.join(ROOT, "include", "bmo.h")).read()
+
+
+def _c_functions():
+    """name -> number of parameters, from the declarations of include/bmo.h"""
+    out = {}
+    for m in re.finditer(r"^(?:int|const char\*)\s+(bmo_[a-z_]+)\s*\(([^;]*?)\)\s*;", HDR, flags=re.M | re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def _split_top(s):
+    parts, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return parts
+
+
+def test_every_ccall_binds_a_declared_symbol_with_its_arity():
+    decl = _c_functions()
+    calls = re.findall(r"ccall\(\(:(bmo_[a-z_]+), LIBBMO\),\s*(\w+),\s*\(", JL)
+    assert {"bmo_scene_create", "bmo_trace", "bmo_retrace", "bmo_result_view", "bmo_result_free", "bmo_scene_destroy", "bmo_last_error",
+            "bmo_photodetector_field", "bmo_psf_intensity"} <= {c[0] for c in calls}
+    for m in re.finditer(r"ccall\(\(:(bmo_[a-z_]+), LIBBMO\),\s*(\w+),\s*\(", JL):
+        name = m.group(1)
+        assert name in decl, name
+        # the argument-type tuple that follows
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(JL[i], 0)
+            i += 1
+        types = [t for t in _split_top(JL[m.end():i - 1]) if t.strip()]
+        assert len(types) == decl[name], (name, types, decl[name])
+        assert m.group(2) in ("Cint", "Cstring"), name
+
+
+def _enum(name):
+    body = re.search(r"enum %s \{(.*?)\};" % name, re.sub(r"/\*.*?\*/", "", HDR, flags=re.S), flags=re.S).group(1)
+    vals, nxt = {}, 0
+    for item in body.split(","):
+        item = item.strip()
+        if not item:
+            continue
+        if "=" in item:
+            k, v = (x.strip() for x in item.split("="))
+            nxt = int(v)
+        else:
+            k = item
+        vals[k] = nxt
+        nxt += 1
+    return vals
+
+
+def _jl_consts():
+    """const A, B, C = v1, v2, v3   |   const A, B = Int32.(0:1)   |   const A = Int32(3)"""
+    out = {}
+    for m in re.finditer(r"^const ([A-Za-z_0-9, \n]+?) = (.+)$", JL, flags=re.M):
+        names = [n.strip() for n in m.group(1).replace("\n", " ").split(",")]
+        rhs = m.group(2).strip()
+        rng = re.match(r"Int32\.\((\d+):(\d+)\)", rhs)
+        if rng:
+            vals = list(range(int(rng.group(1)), int(rng.group(2)) + 1))
+        else:
+            vals = [int(x) for x in re.findall(r"(?:U?Int32|Cint)\((-?\d+)\)|(?<![\w.])(-?\d+)(?![\w.])", rhs) for x in x if x != ""]
+        if len(vals) == len(names):
+            out.update(dict(zip(names, vals)))
+    return out
+
+
+def test_enum_values_match_the_header():
+    jl = _jl_consts()
+    shape, obj, node, beam = _enum("bmo_shape_kind"), _enum("bmo_object_kind"), _enum("bmo_node_status"), _enum("bmo_beam_kind")
+    for jname, cname in (("K_MESH", "MESH"), ("K_SPHERE", "SPHERE"), ("K_PLANO", "PLANO"), ("K_CONVEX", "CONVEX"), ("K_CONCAVE", "CONCAVE"),
+                         ("K_UNION", "UNION"), ("K_BOX", "BOX"), ("K_CYLINDER", "CYLINDER"), ("K_CUTSPHERE", "CUTSPHERE"), ("K_RING", "RING"),
+                         ("K_PRISM", "PRISM"), ("K_MENISCUS", "MENISCUS"), ("K_ASPH_CONVEX", "ASPH_CONVEX"), ("K_ASPH_CONCAVE", "ASPH_CONCAVE"),
+                         ("K_CYL_CONVEX", "CYL_CONVEX"), ("K_CYL_CONCAVE", "CYL_CONCAVE"), ("K_ACYL_CONVEX", "ACYL_CONVEX"),
+                         ("K_ACYL_CONCAVE", "ACYL_CONCAVE")):
+        assert jl[jname] == shape["BMO_SHAPE_" + cname], jname
+    for jname, cname in (("O_MIRROR", "MIRROR"), ("O_REFRACTIVE", "REFRACTIVE"), ("O_DOUBLET", "DOUBLET"), ("O_THIN_BS", "THIN_BS"),
+                         ("O_PLATE_BS", "PLATE_BS"), ("O_CUBE_BS", "CUBE_BS"), ("O_SPOT", "SPOTDETECTOR"), ("O_PSF", "PSFDETECTOR"),
+                         ("O_INTERSECTABLE", "INTERSECTABLE"), ("O_NONINTERACTABLE", "NONINTERACTABLE"), ("O_POLARIZER", "POLARIZER"),
+                         ("O_PHOTODETECTOR", "PHOTODETECTOR")):
+        assert jl[jname] == obj["BMO_OBJ_" + cname], jname
+    for jname, cname in (("NODE_MISS", "MISS"), ("NODE_STOPPED", "STOPPED"), ("NODE_RMAX", "RMAX"), ("NODE_SPLIT", "SPLIT"),
+                         ("NODE_DETECTED", "DETECTED"), ("NODE_ERR_UNIT", "ERR_UNIT"), ("NODE_GAUSS_DIVERGED", "GAUSS_DIVERGED"),
+                         ("NODE_BLOCKED", "BLOCKED"), ("NODE_ERR_ORTHO", "ERR_ORTHO"), ("NODE_RETRACE_STALE", "RETRACE_STALE")):
+        assert jl[jname] == node["BMO_NODE_" + cname], jname
+    assert (jl["BEAM_RAY"], jl["BEAM_POLARIZED"], jl["BEAM_GAUSSIAN"]) == (beam["BMO_BEAM_RAY"], beam["BMO_BEAM_POLARIZED"], beam["BMO_BEAM_GAUSSIAN"])
+    assert jl["BMO_ABI_VERSION"] == int(re.search(r"#define BMO_ABI_VERSION (\d+)", HDR).group(1)) == bmo.abi.ABI_VERSION
+    assert jl["BMO_ERR_UNSUPPORTED"] == _enum("bmo_status")["BMO_ERR_UNSUPPORTED"]
+    assert (jl["VIEW_HITS"], jl["VIEW_LAST_SEGMENT"], jl["VIEW_SEGMENTS"]) == (bmo.abi.VIEW_HITS, bmo.abi.VIEW_LAST_SEGMENT, bmo.abi.VIEW_SEGMENTS)
+    planes = re.search(r"const PLANES_IN = \((\d+), (\d+), (\d+)\)", JL).groups()
+    assert tuple(int(p) for p in planes) == tuple(bmo.abi.PLANES_IN[k] for k in (0, 1, 2))
+
+
+_CT = {C.c_int32: "Int32", C.c_int64: "Int64", C.c_double: "Float64"}
+
+
+def _jl_type(ct):
+    if ct in _CT:
+        return _CT[ct]
+    if hasattr(ct, "_length_"):  # array
+        return "NTuple{%d,%s}" % (ct._length_, _CT[ct._type_])
+    if hasattr(ct, "_type_"):  # pointer
+        return "Ptr"
+    raise AssertionError(ct)
+
+
+def _jl_struct(name):
+    body = re.search(r"^struct %s\b.*?\n(.*?)^end" % name, JL, flags=re.M | re.S).group(1)
+    body = re.sub(r"#.*", "", body)
+    fields = []
+    for item in re.split(r"[;\n]", body):
+        item = item.strip()
+        if item:
+            fname, ftype = (x.strip() for x in item.split("::"))
+            fields.append((fname, re.sub(r"\s+", "", re.sub(r"Ptr\{.*\}", "Ptr", ftype))))
+    return fields
+
+
+def test_struct_mirrors_follow_the_ctypes_mirrors_field_by_field():
+    for jl_name, ct in (("BmoShape", bmo.abi.Shape), ("BmoObject", bmo.abi.Object), ("BmoSceneDesc", bmo.abi.SceneDesc), ("BmoRayBatch", bmo.abi.RayBatch),
+                        ("BmoTraceOpts", bmo.abi.TraceOpts), ("BmoResultView", bmo.abi.ResultView)):
+        want = [(n, _jl_type(t)) for n, t in ct._fields_]
+        assert _jl_struct(jl_name) == want, jl_name
+    m = re.search(r"@assert sizeof\(BmoShape\) == (\d+) && sizeof\(BmoObject\) == (\d+) && sizeof\(BmoSceneDesc\) == (\d+) && sizeof\(BmoTraceOpts\) == (\d+)", JL)
+    assert tuple(int(x) for x in m.groups()) == (C.sizeof(bmo.abi.Shape), C.sizeof(bmo.abi.Object), C.sizeof(bmo.abi.SceneDesc), C.sizeof(bmo.abi.TraceOpts))
+
+
+def test_every_shape_and_object_kind_of_the_header_is_flattened_or_refused():
+    """Each SDF kind the engine knows has a `leaf_record` / `_add_shape!` method, each object kind an `object_record` method; what
+    has none ends in the BmoUnsupported fallback methods."""
+    for t in ("SphereSDF", "PlanoSurfaceSDF", "ConvexSphericalSurfaceSDF", "ConcaveSphericalSurfaceSDF", "BoxSDF", "CylinderSDF", "CutSphereSDF",
+              "RingSDF", "RightAnglePrismSDF", "ConvexAsphericalSurfaceSDF", "ConcaveAsphericalSurfaceSDF", "ConvexCylinderSDF", "ConcaveCylinderSDF",
+              "AconvexCylinderSDF", "AconcaveCylinderSDF"):
+        assert re.search(r"leaf_record\(s::%s\)" % t, JL), t
+        assert re.search(r"local_bound\(s::(%s|AbstractAsphericalSurfaceSDF|AbstractAcylindricalSurfaceSDF)\)" % t, JL), t
+    for t in ("Mesh", "UnionSDF", "MeniscusLensSDF", "AbstractSDF", "AbstractShape"):
+        assert re.search(r"_add_shape!\((tb)?::SceneTables, \w+::%s\)" % t, JL) or re.search(r"_add_shape!\(::SceneTables, \w+::%s\)" % t, JL), t
+    for t in ("AbstractReflectiveOptic", r"Union\{Lens, Prism\}", "DoubletLens", "ThinBeamsplitter", "AbstractPlateBeamsplitter", "CubeBeamsplitter",
+              "Spotdetector", "PSFDetector", "Photodetector", "IntersectableObject", "NonInteractableObject", "PolarizationFilter", "AbstractObject"):
+        assert re.search(r"object_record\(tb, o::%s\)" % t, JL), t
+    assert JL.count("throw(BmoUnsupported(") >= 5
