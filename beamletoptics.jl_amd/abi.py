@@ -174,6 +174,7 @@ def load_engine():
     lib.bmo_retrace_device.argtypes = [vp, vp, vp, C.POINTER(TraceOpts), C.POINTER(vp)]
     dp = C.POINTER(C.c_double)
     lib.bmo_photodetector_field.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp]
+    lib.bmo_gauss_parameters.argtypes = [vp, C.c_int64, dp, C.c_int32, dp]
     lib.bmo_psf_intensity.argtypes = [C.c_void_p, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp, dp]
     _engine = lib
     return lib

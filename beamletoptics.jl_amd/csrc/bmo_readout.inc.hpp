@@ -203,6 +203,36 @@ __global__ void pd_prepare_kernel(int64_t n_hits, const int32_t* __restrict__ se
     s[9] = (opl - len_total) / s[4] * 6.283185307179586;  // ref_ϕ = Δl / λ * 2π
 }
 
+// point_on_beam(gauss.chief, z) (Beam.jl:177-205) on the compact segment table of beamlet h, and the chief / waist / divergence rays
+// of the segment it selects: what gauss_parameters(gauss, z) (Gaussian.jl:298-353) starts from.
+__device__ __forceinline__ RayS pd_ray_of(const double* __restrict__ segs, int64_t total_segs, int b, int64_t seg) {
+    RayS r;
+    const double* q = segs + (int64_t)(8 * b) * total_segs + seg;
+    r.pos = {q[0], q[total_segs], q[2 * total_segs]};
+    r.dir = {q[3 * total_segs], q[4 * total_segs], q[5 * total_segs]};
+    r.n = q[6 * total_segs];
+    return r;
+}
+__device__ __forceinline__ void pd_locate(double z, int64_t s0, int ns, double l_parent, const double* __restrict__ segs, const double* __restrict__ cum,
+                                          int64_t total_segs, const RayS& c_last, RayS& cr, RayS& wr, RayS& dr, d3& p0) {
+    const int64_t last = s0 + ns - 1;
+    int64_t seg = last;
+    if (ns > 1 && z < cum[last - 1]) {  // first ray (but the last) whose cumulative length exceeds z
+        seg = s0;
+        while (!(z < cum[seg])) ++seg;  // terminates: z < cum[last - 1]
+        const double len = segs[7 * total_segs + seg];
+        const double bb = cum[seg] - z;
+        const RayS c = pd_ray_of(segs, total_segs, 0, seg);
+        p0 = axpy3(c.pos, len - bb, c.dir);
+    } else {
+        const double temp = ns > 1 ? cum[last - 1] : l_parent;
+        p0 = axpy3(c_last.pos, z - temp, c_last.dir);
+    }
+    cr = seg == last ? c_last : pd_ray_of(segs, total_segs, 0, seg);
+    wr = pd_ray_of(segs, total_segs, 1, seg);
+    dr = pd_ray_of(segs, total_segs, 2, seg);
+}
+
 struct PdGeom {
     double p[3];   // position(shape(pd))
     double ox[3];  // T[k,1] = orientation[1,k]: the x step in world coordinates (Photodetector.jl:76, :91-95)
@@ -227,38 +257,17 @@ __global__ __launch_bounds__(256) void pd_field_kernel(int64_t n_hits, int64_t h
         const double* s = hs + h * PD_HS;
         const int64_t s0 = seg_start[h];
         const int ns = hit_nseg[h];
-        auto ray_of = [&](int b, int64_t seg) {
-            RayS r;
-            const double* q = segs + (int64_t)(8 * b) * total_segs + seg;
-            r.pos = {q[0], q[total_segs], q[2 * total_segs]};
-            r.dir = {q[3 * total_segs], q[4 * total_segs], q[5 * total_segs]};
-            r.n = q[6 * total_segs];
-            return r;
-        };
         const int64_t last = s0 + ns - 1;
-        const RayS c_last = ray_of(0, last);
+        const RayS c_last = pd_ray_of(segs, total_segs, 0, last);
         // projection of the detector point on the optical axis of the last chief ray
         const d3 dp = sub3(p1, c_last.pos);
         const double l1 = dot3(dp, c_last.dir);
         const d3 p2 = axpy3(c_last.pos, l1, c_last.dir);
         const double r = norm3(sub3(p1, p2));
         const double z = s[7] + l1;
-        // point_on_beam(gauss.chief, z): first ray (but the last) whose cumulative length exceeds z
-        int64_t seg = last;
+        RayS cr, wr, dr;
         d3 p0;
-        if (ns > 1 && z < cum[last - 1]) {
-            seg = s0;
-            while (!(z < cum[seg])) ++seg;  // terminates: z < cum[last - 1]
-            const double len = segs[7 * total_segs + seg];
-            const double bb = cum[seg] - z;
-            const RayS cr = ray_of(0, seg);
-            p0 = axpy3(cr.pos, len - bb, cr.dir);
-        } else {
-            const double temp = ns > 1 ? cum[last - 1] : s[0];
-            p0 = axpy3(c_last.pos, z - temp, c_last.dir);
-        }
-        const RayS cr = seg == last ? c_last : ray_of(0, seg);
-        const RayS wr = ray_of(1, seg), dr = ray_of(2, seg);
+        pd_locate(z, s0, ns, s[0], segs, cum, total_segs, c_last, cr, wr, dr, p0);
         double w, R, psi, w0;
         gauss_parameters_at(cr, wr, dr, p0, s[4], w, R, psi, w0);
         // electric_field(gauss, r, z) Gaussian.jl:381-392
@@ -295,7 +304,73 @@ __global__ void pd_reduce_kernel(const double2* __restrict__ partial, int32_t n_
     field[pt] = make_double2(field[pt].x + re, field[pt].y + im);
 }
 
+// gauss_parameters(gauss, z) for one beamlet (slot 0 of the per-hit tables) at n values of z: the same gather / prepare / locate /
+// gauss_parameters_at sequence the Photodetector field runs per grid point
+__global__ void gp_pick_kernel(int64_t canon, const int32_t* __restrict__ order, const int32_t* __restrict__ nseg, const double* __restrict__ aux,
+                               const double* __restrict__ lambda, int32_t* __restrict__ hit_nseg, int32_t* __restrict__ node_hit, double* __restrict__ hs) {
+    const int32_t nd = order[canon];
+    hit_nseg[0] = nseg[nd];
+    node_hit[nd] = 0;
+    hs[0] = aux[(int64_t)nd * 4 + 0];
+    hs[1] = aux[(int64_t)nd * 4 + 1];
+    hs[2] = aux[(int64_t)nd * 4 + 2];
+    hs[3] = aux[(int64_t)nd * 4 + 3];
+    hs[4] = lambda[nd];
+    hs[5] = 1.0;
+}
+__global__ void gp_eval_kernel(int32_t n, const double* __restrict__ zs, int ns, int64_t total_segs, const double* __restrict__ segs, const double* __restrict__ cum,
+                               const double* __restrict__ hs, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RayS c_last = pd_ray_of(segs, total_segs, 0, ns - 1);
+    RayS cr, wr, dr;
+    d3 p0;
+    pd_locate(zs[i], 0, ns, hs[0], segs, cum, total_segs, c_last, cr, wr, dr, p0);
+    double w, R, psi, w0;
+    gauss_parameters_at(cr, wr, dr, p0, hs[4], w, R, psi, w0);
+    out[4 * i + 0] = w;
+    out[4 * i + 1] = R;
+    out[4 * i + 2] = psi;
+    out[4 * i + 3] = w0;
+}
+
 }  // namespace
+
+extern "C" int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const double* zs, int32_t n, double* out) {
+    if (!res || !zs || !out || n <= 0) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: bad argument");
+    if (res->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: not a GaussianBeamlet solution");
+    if (node < 0 || node >= res->n_nodes) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: bad beamlet index");
+    if (!res->has_log) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: the solution was solved with record_segments = 0 (no segments to evaluate)");
+    HIP_TRY(hipSetDevice(res->device));
+    int rc;
+    DevBuf hit_nseg, node_hit, seg_start, hs, segs, cum, d_z, d_out;
+    if ((rc = hit_nseg.alloc(4)) || (rc = node_hit.alloc((size_t)res->n_nodes * 4)) || (rc = seg_start.alloc(4)) || (rc = hs.alloc(PD_HS * 8)) ||
+        (rc = d_z.alloc((size_t)n * 8)) || (rc = d_out.alloc((size_t)n * 32)))
+        return rc;
+    hipStream_t st = 0;
+    HIP_TRY(hipMemsetAsync(node_hit.p, 0xFF, (size_t)res->n_nodes * 4, st));
+    HIP_TRY(hipMemsetAsync(hs.p, 0, PD_HS * 8, st));
+    HIP_TRY(hipMemsetAsync(seg_start.p, 0, 4, st));
+    hipLaunchKernelGGL(gp_pick_kernel, dim3(1), dim3(1), 0, st, node, (const int32_t*)res->order.p, (const int32_t*)res->n_nseg.p, (const double*)res->n_aux.p,
+                       (const double*)res->n_lambda.p, (int32_t*)hit_nseg.p, (int32_t*)node_hit.p, (double*)hs.p);
+    int32_t ns = 0;
+    HIP_TRY(hipMemcpyAsync(&ns, hit_nseg.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ns <= 0) return fail(BMO_ERR_INTERNAL, "bmo_gauss_parameters: beamlet without segments");
+    if ((rc = segs.alloc((size_t)ns * PD_SEG_PLANES * 8)) || (rc = cum.alloc((size_t)ns * 8))) return rc;
+    for (const Chunk& c : res->chunks)
+        if (c.count > 0)
+            hipLaunchKernelGGL(pd_gather_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, st, c, (const int32_t*)node_hit.p,
+                               (const int32_t*)seg_start.p, (int64_t)ns, (double*)segs.p, (double*)hs.p);
+    hipLaunchKernelGGL(pd_prepare_kernel, dim3(1), dim3(256), 0, st, (int64_t)1, (const int32_t*)seg_start.p, (const int32_t*)hit_nseg.p, (int64_t)ns,
+                       (const double*)segs.p, (double*)cum.p, (double*)hs.p);
+    HIP_TRY(hipMemcpyAsync(d_z.p, zs, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gp_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const double*)d_z.p, (int)ns, (int64_t)ns, (const double*)segs.p,
+                       (const double*)cum.p, (const double*)hs.p, (double*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return BMO_OK;
+}
 
 extern "C" int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, const double position[3], const double orientation[9], const double* xs,
                                        const double* ys, int32_t nx, int32_t ny, double* field_inout, double* kernel_ms) {

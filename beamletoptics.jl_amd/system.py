@@ -373,6 +373,14 @@ class EngineSolution:
         except Exception:
             pass
 
+    def gauss_parameters(self, node, zs):
+        """bmo_gauss_parameters: rows (w, R, psi, w0) of beamlet `node` (result order) at the distances `zs` along the beam."""
+        dp = C.POINTER(C.c_double)
+        z = np.ascontiguousarray(zs, dtype=np.float64)
+        out = np.zeros((len(z), 4))
+        abi.check(self.lib, self.lib.bmo_gauss_parameters(self.handle, int(node), z.ctypes.data_as(dp), len(z), out.ctypes.data_as(dp)), "bmo_gauss_parameters")
+        return out
+
     def photodetector_field(self, slot, position, orientation, xs, ys, field):
         """bmo_photodetector_field: adds the field of the beamlets recorded on detector `slot` to `field[i, j]` (in place)."""
         dp = C.POINTER(C.c_double)
@@ -417,21 +425,17 @@ def release(beams):
         b._solution = None
 
 
-def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=None):
-    """solve_system!(system, beam | beam group; r_max=100, retrace=true) — src/System.jl:444-468.
-
-    Fresh beams are traced; beams solved by an earlier call are RETRACED (System.jl:188-255, :326-428): the stored path is
-    re-walked against the system as it is now, the first ray of every root supplying the (possibly modified) head.
-    Mutates the beam objects (rays, intersections, children) and appends detector data, exactly like the reference
-    (detectors are not reset, Spotdetector.jl / PSFDetector.jl "Reset behavior").  Returns the raw TraceResult.
-    `_trace_fn(scene, bundle, r_max, prev) -> (TraceResult, solution)` swaps the backend (tests: the oracle).
-    """
+def _roots_of(beams):
     if isinstance(beams, bm.BeamGroup):
-        roots = beams.beams
-    elif isinstance(beams, (list, tuple)):
-        roots = list(beams)
-    else:
-        roots = [beams]
+        return beams.beams
+    if isinstance(beams, (list, tuple)):
+        return list(beams)
+    return [beams]
+
+
+def _prepare(system, beams):
+    """(roots, bundle of their first rays, compiled scene, solution of the previous solve of exactly these beams or None)."""
+    roots = _roots_of(beams)
     bundle = bm.RayBundle.from_beams(roots)
     scene = CompiledScene(system, bundle.lambdas)
     prev = getattr(roots[0], "_solution", None) if roots else None
@@ -439,15 +443,19 @@ def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=Non
         same = all(getattr(b, "_solution", None) is prev and getattr(b, "_sol_index", -1) == i for i, b in enumerate(roots))
         if not (same and prev.handle and prev.n_roots == len(roots) and prev.kind == bundle.kind):
             prev = None  # a different grouping than the one that was solved: treat as fresh beams
-    if prev is not None and not retrace:
-        raise NotImplementedError("solve_system(retrace=False) on already solved beams")
-    fn = _trace_fn or (lambda sc, b, rm, pv: _engine_solve(sc, b, rm, pv, device))
-    res, sol = fn(scene, bundle, r_max, prev)
-    _fill_beams(scene, res, roots)
+    return roots, bundle, scene, prev
+
+
+def _apply(scene, res, sol, roots, hit_fix=None):
+    """Fill the beam objects from a TraceResult and append this solve's detector records (detectors are not reset, like the reference:
+    Spotdetector.jl / PSFDetector.jl "Reset behavior").  `hit_fix(slot, hits)` may adjust the rows before they are appended."""
+    nodes = _fill_beams(scene, res, roots)
     for i, b in enumerate(roots):
         b._solution, b._sol_index = sol, i
     for slot, det in enumerate(scene.detectors):
         hits = res.detector_hits(slot)
+        if hit_fix is not None:
+            hits = hit_fix(slot, hits)
         if det.kind == cp.O_SPOT:
             det.data = np.concatenate([det.data, hits[:, 0:2]], axis=0)
         elif det.kind == cp.O_PHOTODETECTOR:
@@ -455,4 +463,80 @@ def solve_system(system, beams, r_max=100, retrace=True, device=0, _trace_fn=Non
                 sol.photodetector_field(slot, det.position(), det.orientation(), det.x, det.y, det.field)
         else:
             det.data = np.concatenate([det.data, hits], axis=0)
+    return nodes
+
+
+def _trace_open_leaves(system, roots, r_max, device):
+    """solve_system!(...; retrace = false) on beams that were solved before (System.jl:449-458, solve_leaf! :470-475): nothing is re-walked;
+    every beam of the trees whose LAST ray has no intersection is traced on from that ray (without a hint, up to r_max rays in the beam),
+    everything else stays as it is.  The open last rays are traced as one fresh batch per distinct remaining length and spliced back."""
+    open_beams, queue = [], list(roots)
+    while queue:  # BFS like solve_system!
+        b = queue.pop(0)
+        queue.extend(b.children)
+        if b.kind == bm.BEAM_GAUSSIAN:
+            raise NotImplementedError("solve_system(retrace=False) on solved GaussianBeamlets: the open-leaf continuation needs the beamlet's "
+                                      "accumulated lengths; retrace them (retrace=True) or release() and solve afresh")
+        if b.rays[-1].intersection is None and len(b.rays) < r_max:
+            open_beams.append(b)
+    by_left = {}
+    for b in open_beams:
+        by_left.setdefault(r_max - len(b.rays) + 1, []).append(b)
+    for left, group in sorted(by_left.items()):
+        heads = []
+        for b in group:
+            last = b.rays[-1]
+            h = bm.Beam.__new__(bm.Beam)
+            h.rays, h.parent, h.children, h.status = [last], None, [], 0
+            heads.append(h)
+        bundle = bm.RayBundle.from_beams(heads)
+        scene = CompiledScene(system, bundle.lambdas)
+        res, sol = _engine_solve(scene, bundle, left, None, device)
+        # optical path length of each beam (parents included) up to the start of its open ray: what PSF records of the continuation add
+        opl0 = []
+        for b in group:
+            acc = 0.0 if b.parent is None else b.parent.optical_path_length()
+            for r in b.rays[:-1]:
+                acc += r.optical_path_length()
+            opl0.append(acc)
+
+        def hit_fix(slot, hits, res=res, scene=scene, opl0=opl0):
+            if scene.detectors[slot].kind != cp.O_PSF or not len(hits):
+                return hits
+            hits = hits.copy()
+            root_of_hit = res.node_root[res.detector_nodes(slot)]
+            hits[:, 6] += np.asarray(opl0)[root_of_hit]
+            return hits
+
+        _apply(scene, res, sol, heads, hit_fix)
+        sol.free()
+        for b, h in zip(group, heads):
+            b.rays[-1:] = h.rays  # the open ray (now with its intersection, if any) and what followed it
+            b.status = h.status
+            for c in h.children:
+                c.parent = b
+            b.children = h.children
+    for b in roots:  # the resident solution no longer describes these beams: the next solve traces them afresh
+        sol = getattr(b, "_solution", None)
+        if sol is not None:
+            sol.free()
+        b._solution = None
+    return None
+
+
+def solve_system(system, beams, r_max=100, retrace=True, device=0):
+    """solve_system!(system, beam | beam group; r_max=100, retrace=true) — src/System.jl:444-468.
+
+    Fresh beams are traced; beams solved by an earlier call are RETRACED (System.jl:188-255, :326-428): the stored path is
+    re-walked against the system as it is now, the first ray of every root supplying the (possibly modified) head.
+    With retrace=False solved beams are not re-walked: only leaves whose last ray has no intersection are traced on (System.jl:470-475).
+    Mutates the beam objects (rays, intersections, children) and appends detector data, exactly like the reference
+    (detectors are not reset, Spotdetector.jl / PSFDetector.jl "Reset behavior").  Returns the raw TraceResult (None for retrace=False
+    on solved beams).  The backend is the HIP engine, always: there is no other.
+    """
+    roots, bundle, scene, prev = _prepare(system, beams)
+    if prev is not None and not retrace:
+        return _trace_open_leaves(system, roots, r_max, device)
+    res, sol = _engine_solve(scene, bundle, r_max, prev, device)
+    _apply(scene, res, sol, roots)
     return res

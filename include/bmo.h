@@ -387,6 +387,13 @@ int bmo_psf_intensity(const double* hits, int64_t n_hits, int32_t hits_on_device
 int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, const double position[3], const double orientation[9], const double* xs,
                             const double* ys, int32_t nx, int32_t ny, double* field_inout, double* kernel_ms);
 
+/* gauss_parameters(gauss, z) — src/Gaussian.jl:298-353 with point_on_beam src/Beam.jl:177-205 — for ONE solved beamlet of `res`
+ * (index in the result's node order) at n distances z along the beam (measured like the reference's: from the start of the root
+ * beamlet, parents included): out[4*i .. 4*i+3] = w (local radius), R (wavefront curvature 1/r), psi (Gouy phase), w0 (local waist).
+ * Evaluated on the GPU by the code bmo_photodetector_field runs per grid point; exists so that the reference's Gaussian
+ * known-answer tests (test/runtests.jl:1811-1932) can be run against the device arithmetic itself.                         */
+int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const double* zs, int32_t n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

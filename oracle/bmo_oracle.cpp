@@ -1872,6 +1872,26 @@ void bmo_cpu_global_E0(const double* in_dir, const double* out_dir, const double
 // interact3d(::Photodetector, gauss, ray_id) Photodetector.jl:69-107 for every beamlet of a solved batch that ended on the
 // photodetector of slot `detector`, in solve order (bundle order x BFS order), added to field (nx*ny complex, (i,j) at [i + nx*j]).
 // electric_field(gauss, r, z) Gaussian.jl:381-392; electric_field(r, z, E0, w0, w, k, psi, R) OpticUtils.jl:87-89.
+// gauss_parameters(gauss, z) (Gaussian.jl:298-353) of beamlet `node` (index in solve order: bundle order x BFS order) at n values of z;
+// out[4*i..] = w, R, psi, w0.  The function the Photodetector read-out and the splitter code of this oracle call.
+int bmo_cpu_gauss_parameters(void* handle, long long node, const double* zs, int n, double* out) {
+    const Result* R = static_cast<const Result*>(handle);
+    if (!R || R->kind != BMO_BEAM_GAUSSIAN || node < 0) return BMO_ERR_INVALID;
+    long long at = 0;
+    for (const auto& root : R->roots) {
+        std::deque<const Node*> queue{root.get()};
+        while (!queue.empty()) {
+            const Node* g = queue.front();
+            queue.pop_front();
+            for (const auto& ch : g->children) queue.push_back(ch.get());
+            if (at++ != node) continue;
+            for (int i = 0; i < n; ++i) gauss_parameters(*g, zs[i], out + 4 * i);
+            return BMO_OK;
+        }
+    }
+    return BMO_ERR_INVALID;
+}
+
 int bmo_cpu_photodetector_field(void* handle, int detector, const double* position, const double* orientation, const double* xs, const double* ys,
                                 int nx, int ny, double* field) {
     const Result* R = static_cast<const Result*>(handle);

@@ -45,6 +45,7 @@ def lib():
         L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
         L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
         L.bmo_cpu_photodetector_field.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp]
+        L.bmo_cpu_gauss_parameters.argtypes = [C.c_void_p, C.c_longlong, dp, C.c_int, dp]
         L.bmo_cpu_psf_intensity.argtypes = [dp, C.c_longlong, dp, dp, dp, dp, dp, C.c_int, dp, dp]
         L.bmo_cpu_psf_intensity.restype = None
         _lib = L
@@ -72,6 +73,15 @@ class Solution:
             self.free()
         except Exception:
             pass
+
+    def gauss_parameters(self, node, zs):
+        """gauss_parameters(beamlet `node`, z) of the oracle's C++ (Gaussian.jl:298-353): rows (w, R, psi, w0)."""
+        z = np.ascontiguousarray(zs, dtype=np.float64)
+        out = np.zeros((len(z), 4))
+        dp = C.POINTER(C.c_double)
+        rc = lib().bmo_cpu_gauss_parameters(self.handle, int(node), z.ctypes.data_as(dp), len(z), out.ctypes.data_as(dp))
+        assert rc == 0, rc
+        return out
 
     def photodetector_field(self, slot, position, orientation, xs, ys, field):
         """Photodetector.jl:69-107 on the CPU for the beamlets of this solution recorded on detector `slot` (adds to field[i, j])."""
@@ -112,13 +122,14 @@ def trace(scene, bundle, r_max=100, threads=1, keep=False, prev=None):
 
 
 def solve_system(system, beams, r_max=100, threads=1):
-    """solve_system! computed by the oracle (fills the same Python beam objects)."""
-    def fn(sc, b, rm, prev):
-        res, sol = trace(sc, b, rm, threads, keep=True, prev=prev)
-        sol.n_roots, sol.kind = b.n, b.kind
-        return res, sol
-
-    return bmo.solve_system(system, beams, r_max=r_max, _trace_fn=fn)
+    """solve_system! computed by the oracle: the host mirror's scene compiler and beam-tree filler (bmo.system._prepare / _apply)
+    around THIS module's trace, so that the reference's known-answer tests can be written against Beam objects.  The product's
+    solve_system has no such switch: it always calls the HIP engine."""
+    roots, bundle, scene, prev = bmo.system._prepare(system, beams)
+    res, sol = trace(scene, bundle, r_max, threads, keep=True, prev=prev)
+    sol.n_roots, sol.kind = bundle.n, bundle.kind
+    bmo.system._apply(scene, res, sol, roots)
+    return res
 
 
 def sdf(scene, shape, p):

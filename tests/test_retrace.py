@@ -239,3 +239,56 @@ def test_gpu_retrace_rejects_mismatched_batch():
     g0, gs0 = _engine_solve(scene0, bundle, 20)
     with pytest.raises(RuntimeError):
         _engine_solve(scene1, scenes.c2_bundle(32), 20, gs0)
+
+
+@pytest.mark.gpu
+def test_solve_again_without_retrace_traces_only_open_leaves():
+    """solve_system!(...; retrace = false) on solved beams (System.jl:449-458, :470-475): beams whose last ray has an intersection are
+    left alone (their detector gets no second record), beams whose last ray is open are traced on from that ray — with the OPL of
+    the whole beam in a PSF record, exactly as if the new object had been there in the first solve."""
+    import math
+
+    from bmo_amd import components as cp
+
+    def build(with_psf):
+        lens = bmo.SphericalLens(60 * mm, -60 * mm, 5 * mm, 25.4 * mm, 1.5)
+        spot = bmo.Spotdetector(4 * mm)            # small: catches the inner rays only
+        bmo.translate3d(spot, [0, 30 * mm, 0])
+        objs = [lens, spot]
+        psf = None
+        if with_psf:
+            psf = bmo.PSFDetector(60 * mm)
+            bmo.translate3d(psf, [0, 50 * mm, 0])
+            objs.append(psf)
+        return bmo.System(objs), spot, psf
+
+    def source():
+        return bmo.UniformDiscSource([0, -20 * mm, 0], [0, 1, 0], 12 * mm, 1.064e-6, num_rays=200, e1=[1, 0, 0])
+
+    # reference behaviour of a fresh solve with the PSF detector in place from the start
+    sys_full, spot_full, psf_full = build(True)
+    fresh = source()
+    bmo.solve_system(sys_full, fresh)
+    # first solve without it, then the detector appears and the beams are solved again without retracing
+    sys0, spot0, _ = build(False)
+    again = source()
+    bmo.solve_system(sys0, again)
+    n_spot = len(spot0.data)
+    open_before = sum(1 for b in again.beams if b.rays[-1].intersection is None)
+    assert 0 < n_spot < 200 and open_before == 200 - n_spot
+    sys1 = bmo.System(sys0.objects() + [bmo.PSFDetector(60 * mm)])
+    psf1 = sys1.objects()[-1]
+    bmo.translate3d(psf1, [0, 50 * mm, 0])
+    assert bmo.solve_system(sys1, again, retrace=False) is None
+    assert len(spot0.data) == n_spot                                   # closed beams were not traced again
+    assert len(psf1.data) == open_before == len(psf_full.data)         # open ones went on to the new detector
+    assert np.array_equal(psf1.data, psf_full.data)                    # hit, dir, OPL of the WHOLE beam, proj, k: as in the fresh solve
+    for a, b in zip(again.beams, fresh.beams):
+        assert len(a.rays) == len(b.rays)
+        for ra, rb in zip(a.rays, b.rays):
+            assert np.array_equal(ra.pos, rb.pos) and np.array_equal(ra.dir, rb.dir)
+            assert (ra.intersection is None) == (rb.intersection is None)
+            if ra.intersection is not None:
+                assert ra.intersection.t == rb.intersection.t and type(ra.intersection.object) is type(rb.intersection.object)
+    bmo.release(again)
+    bmo.release(fresh)
