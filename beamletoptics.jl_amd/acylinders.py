@@ -28,6 +28,12 @@ def make(sh):
         def params(self):
             return [self.radius, self.diameter, self.height, self.conic_constant, self.max_sag[0]]
 
+        def slope_bound(self):
+            """See _AsphericalSurfaceSDF.slope_bound: the same 2D profile, extruded instead of revolved; the extrusion combines the
+            profile term d2 with the exact slab term |x| - h/2 by max / norm(max.(., 0)) (AcylindricalSDF.jl:55-74), which keeps
+            sdf >= dist / K for K >= 1."""
+            return sh._profile_slope_bound(self.radius, self.conic_constant, self.coefficients, self.diameter)
+
         def _local_bound(self):
             zs = [0.0, self.edge_sag_value(), self.max_sag[0]]
             lo, hi = min(zs), max(zs)

@@ -593,14 +593,10 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
 
 // normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88).
-//
-// probe mode (decision aid, never part of a result): returns {f(p + hd*dir), f(p - hd*dir), 0} for the arg-min child's sdf f,
-// evaluated at the stencil call site, so that the caller can estimate the directional derivative dir . grad f with TWO plain
-// evaluations instead of a dual-number gradient (see intersect_shape, start classification).
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child, bool probe, const d3& dir, double hd) {
+BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child) {
     CShape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
-    if (!probe) {
+    {
 #if defined(BMO_EMU_STATS)
         ++g_emu_normal;
 #endif
@@ -615,25 +611,20 @@ BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_ch
     const double e = S.grad_h;
     double g0 = 0, g1 = 0, g2 = 0;
     BMO_NOUNROLL
-    for (int q = probe ? 6 : 0; q < (probe ? 8 : 6); ++q) {  // +x -x +y -y +z -z ; the untouched components get +0.0 / -0.0 like Point3(eps,0,0)
+    for (int q = 0; q < 6; ++q) {  // +x -x +y -y +z -z ; the untouched components get +0.0 / -0.0 like Point3(eps,0,0)
         const int ax = q >> 1;
         const bool minus = q & 1;
         double ox = ax == 0 ? e : 0.0, oy = ax == 1 ? e : 0.0, oz = ax == 2 ? e : 0.0;
         v3<double> pt = minus ? v3<double>{p.x - ox, p.y - oy, p.z - oz} : v3<double>{p.x + ox, p.y + oy, p.z + oz};
-        if (q == 6) pt = v3<double>{p.x + hd * dir.x, p.y + hd * dir.y, p.z + hd * dir.z};
-        if (q == 7) pt = v3<double>{p.x - hd * dir.x, p.y - hd * dir.y, p.z - hd * dir.z};
 #if defined(BMO_EMU_STATS)
         ++g_emu_sdf_leaf;
 #endif
         double v = sdf_simple<double, ASPH>(S, sh, pt);
         // f(p+h) - f(p-h): the '+' value is stored first, the '-' value subtracted from it
-        if (q == 6) g0 = v;
-        else if (q == 7) g1 = v;
-        else if (ax == 0) g0 = minus ? g0 - v : v;
+        if (ax == 0) g0 = minus ? g0 - v : v;
         else if (ax == 1) g1 = minus ? g1 - v : v;
         else g2 = minus ? g2 - v : v;
     }
-    if (probe) return d3{g0, g1, 0.0};
     return normalize_div(d3{g0, g1, g2});
 }
 
@@ -726,7 +717,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
     d3 pos = pos0, dir = dir0;
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
     int i_out = 1, i_in = 1;
-    bool back = false, classify_full = false;
+    bool back = false;
     // `pending`: this lane stands on the surface (start classification) or has converged (hit) and needs a normal.  The normal
     // (dual-number gradient, by far the most expensive piece) is evaluated only when EVERY lane of the wave still inside this
     // loop is pending, so the wave runs that code once per round instead of once per iteration in which some lane converges.
@@ -787,32 +778,11 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         }
         if (!BMO_WAVE_ALL(pending)) continue;
         pending = false;
-        const bool probe = phase == CLASSIFY && exact && !classify_full && s.bs_radius > 0.0;
-        // single normal evaluation site (classification on the surface, or hit)
-        // Start classification (AbstractSDF.jl:152-165) only needs the SIGN of dot(dir, normal): entering or leaving.  For an exact
-        // (unit-gradient) sdf that sign is the sign of the directional derivative of the arg-min child's sdf f along dir.  Two plain
-        // evaluations at p +- hd*dir (hd = 1e-5 bounding radii) give the one-sided slopes g+ and g-: for a smooth f they agree to
-        // hd*f'' ~ 1e-5 and equal the derivative to that accuracy (rounding ~1e-17/hd); the reference's normal gives
-        // dot = that derivative to 1e-8 (dual numbers ~1e-15; its central-difference fallback ~1e-8).  The shortcut is taken only
-        // when |g+ - g-| <= 1e-3 (no kink of f within hd of p along the ray) and |g| > 0.05 (less than 87.1 deg from the normal);
-        // grazing rays, kinks, NaNs and inexact (aspheric) shapes take the reference's normal.  The hit normal further down is
-        // always the reference's.
-        const double hd = 1e-5 * s.bs_radius;
-        const d3 n = normal_any<ASPH>(S, s, pos, bc, probe, dir, hd);
+        // single normal evaluation site: the reference's normal3d, for the start classification on the surface
+        // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the hit
+        const d3 n = normal_any<ASPH>(S, s, pos, bc);
         if (phase == CLASSIFY) {
-            bool entering;
-            if (probe) {
-                const double gp = (n.x - d) / hd, gm = (d - n.y) / hd, g = 0.5 * (gp + gm);
-                if (!(fabs(gp - gm) <= 1e-3) || !(fabs(g) > 0.05)) {
-                    classify_full = true;
-                    pending = true;  // same point, the reference's normal this time
-                    continue;
-                }
-                entering = g < 0.0;
-            } else {
-                entering = dot3(dir, n) <= 0;
-            }
-            if (entering) {
+            if (dot3(dir, n) <= 0) {  // entering
                 phase = INSIDE;
                 t_in = 0.0;
                 i_in = 1;

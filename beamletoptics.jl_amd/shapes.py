@@ -418,6 +418,18 @@ def max_aspheric_value(c, k, coeffs, d):
     return f(r_max), r_max
 
 
+def _profile_slope_bound(radius, conic_constant, coefficients, diameter, samples=4097):
+    g_max = 0.0
+    for r in np.linspace(0.0, diameter / 2, samples):
+        g = gradient_aspheric_equation(float(r), 1 / radius, conic_constant, coefficients)
+        z = aspheric_equation(float(r), 1 / radius, conic_constant, coefficients)
+        if math.isnan(g) or math.isnan(z) or math.isinf(g):
+            return None
+        g_max = max(g_max, abs(g))
+    g_max *= 1.05
+    return math.sqrt(1 + g_max * g_max)
+
+
 class _AsphericalSurfaceSDF(AbstractSDF):
     flags = FLAG_INEXACT  # first-order distance estimate: bounding-sphere culls only
 
@@ -434,6 +446,17 @@ class _AsphericalSurfaceSDF(AbstractSDF):
 
     def params(self):
         return [self.radius, self.conic_constant, self.diameter, self.max_sag[0]]
+
+    def slope_bound(self):
+        """K >= 1 with  sdf(p) >= dist(p, solid) / K  for every p outside the solid (None: no such bound, the shape is not culled).
+
+        The aspheric "sdf" is a first-order estimate: |z - z(r)| / sqrt(1 + z'(r)^2) over the aperture, exact distances to the closing
+        segments of the 2D perimeter divided by sqrt(1 + z'(d/2)^2) elsewhere, and the minimum of such terms
+        (AsphericalLensSDF.jl:186-307).  |z - z(r)| is the distance to the surface point straight above / below p, so it is at
+        least dist(p, solid); the segments are part of the solid, so their distances are at least dist(p, solid) too.  Each term
+        is therefore >= dist(p, solid) / sqrt(1 + G^2) with G the largest |z'| over [0, d/2] — taken from 4097 samples, the
+        edge included, with 5 % on top.  A profile whose conic term runs out of its domain inside the aperture (NaN) gets none."""
+        return _profile_slope_bound(self.radius, self.conic_constant, self.coefficients, self.diameter)
 
     def _local_bound(self):
         # the closed 2D perimeter lives in |r| <= d/2, z between 0, the edge sag and the extreme sag

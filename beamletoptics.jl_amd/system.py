@@ -50,6 +50,8 @@ class CompiledScene:
                 media.append([float(fn(l)) for l in self.lambdas])
             return media_ids[key]
 
+        slope = {}  # shape id -> K of "sdf >= dist / K" (1 for exact sdfs; None: no bound, never culled)
+
         def add_shape(s):
             if id(s) in self._shape_ids:
                 return self._shape_ids[id(s)]
@@ -82,17 +84,23 @@ class CompiledScene:
                 c, r = s.world_bound()
                 if any(shapes[i].flags & sh.FLAG_INEXACT for i in ids):
                     rec.flags |= sh.FLAG_INEXACT
+                ks = [slope[i] for i in (ids[:2] if s.kind == sh.K_MENISCUS else ids)]  # min over children: the weakest bound holds
+                slope[sid] = None if any(k is None for k in ks) else max(ks)
             elif s.kind in (sh.K_ASPH_CONVEX, sh.K_ASPH_CONCAVE, sh.K_ACYL_CONVEX, sh.K_ACYL_CONCAVE):
                 rec.child_begin = len(coefs)
                 rec.child_count = len(s.coefficients)
                 coefs.extend(s.coefficients)
                 rec.flags |= sh.FLAG_INEXACT
                 c, r = s.world_bound()
+                slope[sid] = s.slope_bound()
             else:
                 c, r = s.world_bound()
-            if cull:
+            K = slope.setdefault(sid, 1.0)
+            if cull and K is not None:
+                # outside the inflated sphere dist(p, solid) >= K * (r * 1e-6 + 1 um), hence sdf(p) >= r * 1e-6 + 1 um: the
+                # reference's start classification is "outside" (> 1e-9) and its hit test (< 1e-10) can never fire
                 rec.bs_center[:] = list(c)
-                rec.bs_radius = r * (1 + _BS_REL) + _BS_ABS
+                rec.bs_radius = r + K * (r * _BS_REL + _BS_ABS)
             else:
                 rec.bs_center[:] = [0.0, 0.0, 0.0]
                 rec.bs_radius = -1.0

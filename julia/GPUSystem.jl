@@ -134,6 +134,7 @@ tup3(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]))
 pad8(v...) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, 8)
 
 mutable struct SceneTables
+    slope::Vector{Float64}                         # per shape id: K of "sdf >= dist / K" (1 for exact sdfs, NaN: no bound => never culled)
     shapes::Vector{BmoShape}
     shape_refs::Vector{Any}                        # Julia shape of every shape id (Intersection.shape is rebuilt from it)
     shape_ids::IdDict{Any, Int32}
@@ -147,7 +148,7 @@ mutable struct SceneTables
     detectors::Vector{Any}
     lambdas::Vector{Float64}
 end
-SceneTables(λs) = SceneTables(BmoShape[], Any[], IdDict{Any, Int32}(), Tuple{NTuple{3, Float64}, Float64}[], Int32[], Float64[], Float64[],
+SceneTables(λs) = SceneTables(Float64[], BmoShape[], Any[], IdDict{Any, Int32}(), Tuple{NTuple{3, Float64}, Float64}[], Int32[], Float64[], Float64[],
                               Vector{Float64}[], IdDict{Any, Int32}(), BmoObject[], Any[], λs)
 
 # miss-cull inflation of bounding spheres (DESIGN.md "miss cull"; beamletoptics.jl_amd/system.py _BS_REL, _BS_ABS)
@@ -222,13 +223,32 @@ leaf_record(s::AconcaveCylinderSDF) = (K_ACYL_CONCAVE, pad8(s.radius, s.diameter
 leaf_record(s::AbstractShape) = throw(BmoUnsupported("shape type $(typeof(s))"))
 has_coefficients(s) = s isa AbstractAsphericalSurfaceSDF || s isa AbstractAcylindricalSurfaceSDF
 
-function push_shape!(tb::SceneTables, s, rec_fields, bound)
+"""
+K >= 1 with sdf(p) >= dist(p, solid) / K outside the solid, for the first-order aspheric / acylindric distance estimates
+(AsphericalLensSDF.jl:186-307): K = sqrt(1 + G^2), G = 1.05 x the largest |z'(r)| over 4097 samples of [0, d/2]; NaN when the conic
+term leaves its domain inside the aperture (then the shape is never culled).  Derivation: beamletoptics.jl_amd/shapes.py slope_bound.
+"""
+function slope_bound(s)
+    g_max = 0.0
+    for r in range(0.0, s.diameter / 2; length = 4097)
+        g = gradient_aspheric_equation(r, 1 / s.radius, s.conic_constant, s.coefficients)[1]
+        z = aspheric_equation(r, 1 / s.radius, s.conic_constant, s.coefficients)
+        (isnan(g) || isnan(z) || isinf(g)) && return NaN
+        g_max = max(g_max, abs(g))
+    end
+    g_max *= 1.05
+    return sqrt(1 + g_max^2)
+end
+
+function push_shape!(tb::SceneTables, s, rec_fields, bound, K::Float64 = 1.0)
     kind, child_begin, child_count, tri_begin, tri_count, flags, p = rec_fields
     c, r = bound
+    push!(tb.slope, K)
+    bs_radius = isnan(K) ? -1.0 : r + K * (r * BS_REL + BS_ABS)   # outside it sdf >= r*1e-6 + 1 um: the reference can only return `nothing`
     dir = orientation(s)                           # SphereSDF: identity (SphericalLensSDF.jl:82-84)
     tdir = s isa AbstractSDF ? transposed_orientation(s) : transpose(dir)   # the stored copy(dir') of AbstractSDF.jl:20-27
     push!(tb.shapes, BmoShape(kind, child_begin, child_count, tri_begin, tri_count, flags, tup3(position(s)), rowmajor(dir), rowmajor(tdir), p,
-                              c, r * (1 + BS_REL) + BS_ABS))
+                              c, bs_radius))
     push!(tb.shape_refs, s)
     push!(tb.bounds, bound)
     id = Int32(length(tb.shapes) - 1)
@@ -259,7 +279,8 @@ function _add_shape!(tb::SceneTables, u::UnionSDF)
     append!(tb.children, ids)
     flags = any(tb.shapes[i + 1].flags & SHAPE_FLAG_INEXACT != 0 for i in ids) ? SHAPE_FLAG_INEXACT : Int32(0)
     bound = enclose([tb.bounds[i + 1] for i in ids])
-    return push_shape!(tb, u, (K_UNION, child_begin, Int32(length(ids)), Int32(0), Int32(0), flags, pad8()), bound)
+    K = maximum(tb.slope[i + 1] for i in ids)       # min over children: the weakest bound holds (NaN propagates)
+    return push_shape!(tb, u, (K_UNION, child_begin, Int32(length(ids)), Int32(0), Int32(0), flags, pad8()), bound, K)
 end
 function _add_shape!(tb::SceneTables, ml::MeniscusLensSDF)
     # children = {convex, cylinder, concave}; their pos / dir are expressed in the meniscus frame (MeniscusLensSDF.jl:42-46)
@@ -269,7 +290,8 @@ function _add_shape!(tb::SceneTables, ml::MeniscusLensSDF)
     flags = any(tb.shapes[i + 1].flags & SHAPE_FLAG_INEXACT != 0 for i in ids) ? SHAPE_FLAG_INEXACT : Int32(0)
     c_local, r = enclose([tb.bounds[ids[1] + 1], tb.bounds[ids[2] + 1]])   # max(min(convex, cylinder), -concave) lies inside convex U cylinder
     c = tup3(position(ml) + orientation(ml) * Point3{Float64}(c_local...))
-    return push_shape!(tb, ml, (K_MENISCUS, child_begin, Int32(3), Int32(0), Int32(0), flags, pad8()), (c, r))
+    K = max(tb.slope[ids[1] + 1], tb.slope[ids[2] + 1])
+    return push_shape!(tb, ml, (K_MENISCUS, child_begin, Int32(3), Int32(0), Int32(0), flags, pad8()), (c, r), K)
 end
 function _add_shape!(tb::SceneTables, s::AbstractSDF)
     kind, p = leaf_record(s)
@@ -278,7 +300,8 @@ function _add_shape!(tb::SceneTables, s::AbstractSDF)
         child_begin, child_count, flags = Int32(length(tb.coefs)), Int32(length(s.coefficients)), SHAPE_FLAG_INEXACT
         append!(tb.coefs, Float64.(s.coefficients))
     end
-    return push_shape!(tb, s, (kind, child_begin, child_count, Int32(0), Int32(0), flags, p), world_bound(s))
+    K = has_coefficients(s) ? slope_bound(s) : 1.0
+    return push_shape!(tb, s, (kind, child_begin, child_count, Int32(0), Int32(0), flags, p), world_bound(s), K)
 end
 _add_shape!(::SceneTables, s::AbstractShape) = throw(BmoUnsupported("shape type $(typeof(s))"))
 

@@ -74,6 +74,35 @@ inline bool operator>(const Dual& a, double b) { return a.v > b; }
 // 0*Inf = NaN every concave-surface normal (norm(max.(d, 0)) of a zero vector inside the cylinder part, SphericalLensSDF.jl:159-170)
 // falls back to central differences, whose 1e-8 stencil pokes through the < 1e-8-thin wedge near the apex: the spot is 1e-3 m
 // and the on-axis ray gets a NaN normal.  With the rule below the dual gradient is valid there: spot 1.3e-7 m, 1000 of 1000 rays.
+//
+// Where the rule can come from upstream (round 2; written from the packages' published sources as far as they can be restated
+// without network access — nothing of them is vendored under /root/reference — so file names are given, line numbers are not):
+//   (A) ForwardDiff src/dual.jl builds sqrt(::Dual) from DiffRules' `@define_diffrule Base.sqrt(x) = :(inv(2 * sqrt($x)))` through
+//       `dual_definition_retval(::Val{T}, val, deriv, partials) = Dual{T}(val, deriv * partials)`; src/partials.jl has
+//       `*(partials::Partials, x::Real) = Partials(scale_tuple(partials.values, x))` and, under `if NANSAFE_MODE_ENABLED`, the
+//       variant with `x = ifelse(!isfinite(x) && iszero(partials), one(x), x)`.  NANSAFE_MODE_ENABLED is the preference
+//       "nansafe_mode" (src/prefs.jl), default false in 0.10.x and, as far as recalled, in 1.0.x.  Default build: 0 * Inf = NaN.
+//   (B) GeometryBasics 0.5 dropped StaticArrays and defines its own fixed-size vectors (src/fixed_arrays.jl); recalled there:
+//       `LinearAlgebra.norm(a::StaticVector) = sqrt(dot(a, a))` and `LinearAlgebra.normalize(a::StaticVector) = a ./ norm(a)`.  With
+//       these, norm(max.(d, 0)) of a zero vector IS sqrt(Dual(0, zeros)) and (A) decides.  If instead Point2 fell through to
+//       LinearAlgebra's generic norm, `generic_norm2` returns `maxabs` as soon as `iszero(maxabs)` — a Dual(0, zeros), no sqrt, no
+//       NaN — which is observationally the rule coded below (for non-zero vectors both forms give sqrt of the same left-folded sum).
+//   So the reference's own tests decide between "default ForwardDiff + sqrt(dot)" (NaN) and "(A) NaN-safe or (B) generic norm"
+//   (zero partials kept).  What NaN would mean, quantitatively: the dual gradient of EVERY point on a concave spherical surface
+//   inside its aperture is NaN (d = (r - dia/2, |y + sag/2| - sag/2) has both components <= 0 there), so normal_fd falls back to
+//   numeric_gradient with its +-1e-8 stencil.  ConcaveSphericalSurfaceSDF is a cylinder of height sag minus a ball whose top touches
+//   the cylinder's cap at the apex, so the glass under the cap is y_cap - y_sphere = r^2 / (2R) thick at distance r from the axis:
+//   thinner than the stencil for r < sqrt(2 R 1e-8) (24 um at R = 30 mm).  Inside that disc the +y stencil point leaves the cylinder,
+//   max(sdf1, -sdf2) switches branch, and the y difference comes out as -|y| instead of -2e-8: a normal that is wrong by tens of
+//   degrees.  The reference's "Double Gauss lens / point source (narrow)" test sends 1000 rays through exactly that disc of several
+//   concave surfaces and requires a 2e-7 m spot; measured with this oracle: 1.3e-7 m with zero partials kept, 1e-3 m with NaN
+//   (build with -DBMO_SQRT_PLAIN to see it).  That test passing upstream is incompatible with the NaN variant.
+//   One reference assertion points the other way (the cube splitter rotated by pi/2 returning `direction == [0, 1, 0]` exactly,
+//   runtests.jl:2629-2630, needs the exactly axis-aligned normal that only the numeric fallback yields on the prism's entry face,
+//   where norm(max.(q, 0)) is again the norm of a zero vector); tests/test_oracle_kat2.py keeps it at one unit of cos(pi/2) =
+//   6.1e-17.  Both cannot hold under one rule for the same expression; the physical KAT has a 5000x margin, the exact-equality one
+//   rides on the last bit.  Status: UNPINNED at the bit level until someone runs the reference; the rule is applied in
+//   the oracle and in the engine alike (csrc/bmo_lane.hpp jsqrt), so it cannot make them disagree with each other.
 inline Dual jsqrt(const Dual& a) {
     double s = std::sqrt(a.v);
     double d = 1.0 / (2.0 * s);

@@ -73,3 +73,48 @@ def test_grazing_rays(oracle):
     b = bmo.RayBundle.rays(pos, np.tile([0.0, 1.0, 0.0], (len(offs), 1)), 1e-6)
     sc = bmo.CompiledScene(system, b.lambdas)
     compare(emu_trace(sc, b, 20), oracle.trace(sc, b, 20), 0.0, "grazing")
+
+
+def test_inexact_sdfs_are_bounded_through_their_slope_bound(oracle):
+    """Aspheric / acylindric "sdfs" are first-order estimates, not distances.  The cull may still skip them because
+    sdf(p) >= dist(p, solid) / K with K = sqrt(1 + max |z'|^2) (shapes.py slope_bound, derived there), and the bounding sphere of
+    such a shape — and of every union / meniscus that contains one — is inflated by K x the usual margin.  Checked here on random
+    lenses from the fuzz menus: K covers the sampled slopes, and outside the sphere the estimate never falls below dist / K."""
+    from test_fuzz import _make
+
+    rng_np = np.random.Generator(np.random.PCG64(2025))
+    rng = np.random.default_rng(5)
+    seen = 0
+    for kind in ["asphere"] * 6 + ["asphere2"] * 6 + ["acylinder"] * 6:
+        lens, _ = _make(rng_np, kind)
+        bmo.xrotate3d(lens, 0.2)
+        bmo.translate3d(lens, [1 * mm, -3 * mm, 2 * mm])
+        sc = bmo.CompiledScene(bmo.System([lens]), [1e-6])
+        top = lens.shape
+        for s in [top] + list(getattr(top, "sdfs", [])):
+            rec = sc._shapes[sc.shape_id(s)]
+            if not (rec.flags & 1):
+                continue
+            c0, r0 = s.world_bound()
+            kids = getattr(s, "sdfs", [s])
+            ks = [k.slope_bound() if hasattr(k, "slope_bound") else 1.0 for k in kids]
+            if any(k is None for k in ks):
+                assert rec.bs_radius < 0  # no bound => never culled
+                continue
+            K = max(ks)
+            assert K >= 1.0 and rec.bs_radius >= r0 + K * 1e-6
+            for k in kids:  # K covers the profile's slope wherever it is sampled
+                if hasattr(k, "slope_bound"):
+                    for r in rng.uniform(0, k.diameter / 2, 64):
+                        g = bmo.shapes.gradient_aspheric_equation(float(r), 1 / k.radius, k.conic_constant, k.coefficients)
+                        assert math.sqrt(1 + g * g) <= K
+            c = np.array(rec.bs_center[:])
+            for _ in range(300):
+                u = rng.normal(size=3)
+                u /= np.linalg.norm(u)
+                p = c + u * rec.bs_radius * (1 + 2 * rng.random())
+                v = oracle.sdf(sc, s, p)
+                assert v >= (np.linalg.norm(p - np.asarray(c0)) - r0) / K * (1 - 1e-9), (kind, type(s).__name__)
+                assert v >= 1e-6  # what the cull needs: far above the reference's 1e-9 / 1e-10 thresholds
+            seen += 1
+    assert seen >= 18
