@@ -1948,9 +1948,9 @@ int bmo_result_view_select(bmo_trace_result* r, uint32_t what, bmo_trace_result_
             HIP_TRY(hipMemcpyAsync(r->h_nseg.p, d_nseg.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
             HIP_TRY(hipMemcpyAsync(r->h_status.p, d_status.p, (size_t)nn * 4, hipMemcpyDeviceToHost, 0));
             HIP_TRY(hipMemcpyAsync(r->h_aux.p, d_aux.p, (size_t)nn * 32, hipMemcpyDeviceToHost, 0));
-            HIP_TRY(hipStreamSynchronize(0));
-            int32_t* lr = r->h_last_rec.as<int32_t>();  // LAST view: record i belongs to node i
+            int32_t* lr = r->h_last_rec.as<int32_t>();  // LAST view: record i belongs to node i (filled while the copies run)
             for (int64_t i = 0; i < nn; ++i) lr[i] = (int32_t)i;
+            HIP_TRY(hipStreamSynchronize(0));  // the staging buffers go back to the pool when this scope ends
         }
         r->nodes_viewed = true;
     }
@@ -1958,9 +1958,9 @@ int bmo_result_view_select(bmo_trace_result* r, uint32_t what, bmo_trace_result_
     for (int d = 0; d < r->n_detectors; ++d) tot += r->det_count[d];
     if ((what & BMO_VIEW_HITS) && !r->hits_viewed) {
         if ((rc = r->h_det.alloc((size_t)tot * 72)) || (rc = r->h_det_node.alloc((size_t)tot * 4))) return rc;
-        if (tot > 0) {
-            HIP_TRY(hipMemcpy(r->h_det.p, r->det_data.p, (size_t)tot * 72, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_det_node.p, r->det_node.p, (size_t)tot * 4, hipMemcpyDeviceToHost));
+        if (tot > 0) {  // queued behind the node tables, completed by the synchronisation at the end of this call
+            HIP_TRY(hipMemcpyAsync(r->h_det.p, r->det_data.p, (size_t)tot * 72, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_det_node.p, r->det_node.p, (size_t)tot * 4, hipMemcpyDeviceToHost, 0));
         }
         r->hits_viewed = true;
     }
@@ -1989,12 +1989,14 @@ int bmo_result_view_select(bmo_trace_result* r, uint32_t what, bmo_trace_result_
                                        (const int32_t*)r->n_nseg.p, nn, (double*)d_rec.p, (int32_t*)d_obj.p, (int32_t*)d_shape.p);
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpy(r->h_rec.p, d_rec.p, (size_t)P * cols * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_rec_obj.p, d_obj.p, (size_t)cols * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_rec_shape.p, d_shape.p, (size_t)cols * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(r->h_rec.p, d_rec.p, (size_t)P * cols * 8, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_rec_obj.p, d_obj.p, (size_t)cols * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipMemcpyAsync(r->h_rec_shape.p, d_shape.p, (size_t)cols * 4, hipMemcpyDeviceToHost, 0));
+            HIP_TRY(hipStreamSynchronize(0));  // the staging buffers go back to the pool when this scope ends
         }
         r->rec_mode = want_mode;
     }
+    HIP_TRY(hipStreamSynchronize(0));
     // what this view shows: the whole log only when asked for it (or when nothing narrower was asked and it is there)
     const int show = (what & BMO_VIEW_SEGMENTS) ? (r->rec_mode == 2 ? 2 : 0) : ((what & BMO_VIEW_LAST_SEGMENT) ? (r->rec_mode == 1 ? 1 : 0) : 0);
     if ((what & BMO_VIEW_LAST_SEGMENT) && !(what & BMO_VIEW_SEGMENTS) && r->rec_mode == 2)

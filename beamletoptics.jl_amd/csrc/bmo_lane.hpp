@@ -546,26 +546,19 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
     // shape first_id + c, no look-up in children[]
     const bool consecutive = uni && (s.flags & BMO_SHAPE_FLAG_CONSECUTIVE);
     const int32_t cb = s.child_begin, first_id = s.tri_begin;
+    const bool all_exact = !(s.flags & BMO_SHAPE_FLAG_INEXACT);
     BMO_NOUNROLL
     for (int q = 0; q < nch; ++q) {
         const int c = q == 0 ? first : (q <= first ? q - 1 : q);
         CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[consecutive ? first_id + BMO_UNIFORM(c) : S.children[cb + BMO_UNIFORM(c)]] : &s);
-        const int32_t ch_flags = ch.flags;  // one batch with the bounding sphere
-        const double ch_r = ch.bs_radius, ch_cx = ch.bs_center[0], ch_cy = ch.bs_center[1], ch_cz = ch.bs_center[2];
-        const double cached = (uni && c < BMO_CC_MAX) ? cc.v[c * cc.stride] : -kinf();  // same batch
+        const double cached = (uni && c < BMO_CC_MAX) ? cc.v[c * cc.stride] : -kinf();
         bool skip = false;
         double lb = -kinf();
-        if (have && !(ch_flags & BMO_SHAPE_FLAG_INEXACT)) {
+        // a union is flagged INEXACT when one of its children is (scene compiler): only then the child's own flag is looked up
+        if (have && c < BMO_CC_MAX && (all_exact || !(ch.flags & BMO_SHAPE_FLAG_INEXACT))) {
             const double bound = best > 0.0 ? best : 0.0;
-            if (ch_r >= 0.0) {
-                const double ox = p.x - ch_cx, oy = p.y - ch_cy, oz = p.z - ch_cz;
-                const double lim = ch_r + bound;
-                skip = (ox * ox + oy * oy) + oz * oz > lim * lim;
-            }
-            if (!skip && c < BMO_CC_MAX) {
-                lb = cached - slack;
-                skip = lb > bound + 1e-12;
-            }
+            lb = cached - slack;
+            skip = lb > bound + 1e-12;
         }
         if (!skip) {
 #if defined(BMO_EMU_STATS)
@@ -584,7 +577,7 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
                 best = jmin(best, v);
             }
         } else if (uni && c < BMO_CC_MAX) {
-            cc.v[c * cc.stride] = lb;  // still a valid lower bound at this point (-inf when only the sphere test skipped it)
+            cc.v[c * cc.stride] = lb;  // still a valid lower bound at this point
         }
     }
     if (uni) cc.prev_best = best_child;

@@ -206,25 +206,30 @@ def pcie_rates(case, r_max, calls):
 
     def with_hits():
         res = host_solve()
+        copy_hits(res)
+        lib.bmo_result_free(res)
+
+    def copy_hits(res):
         for s in range(case.n_det):
             cnt = eng.result_device_hits(res, s)[1]
             w = case.det_cols[s]
             if s not in hit_bufs or hit_bufs[s].shape[0] < cnt:
                 hit_bufs[s] = np.zeros((max(cnt, 1), w))  # the caller's buffer, reused across solves
             eng.result_copy_hit_columns(res, s, w, hit_bufs[s].ctypes.data, cnt)
-        lib.bmo_result_free(res)
 
-    def with_view(what):
+    def with_view(what, packed_hits=False):
         def f():
             res = host_solve()
             v = abi.ResultView()
             abi.check(lib, lib.bmo_result_view_select(res, what, C.byref(v)), "bmo_result_view_select")
+            if packed_hits:
+                copy_hits(res)
             lib.bmo_result_free(res)
         return f
 
     out = {}
     for name, fn, reps in (("with_h2d", with_h2d, 3), ("with_hits_d2h", with_hits, 3),
-                           ("with_last_segment_view", with_view(abi.VIEW_HITS | abi.VIEW_LAST_SEGMENT), 3),
+                           ("with_last_segment_view", with_view(abi.VIEW_LAST_SEGMENT, packed_hits=True), 3),
                            ("with_full_view", with_view(abi.VIEW_HITS | abi.VIEW_SEGMENTS), 2)):
         fn()  # warm-up: pinned pools, page faults
         best = None
@@ -236,7 +241,7 @@ def pcie_rates(case, r_max, calls):
         out[name] = {"ms": best * 1e3, "intersections_per_s": calls / best}
     out["what"] = {"with_h2d": "bmo_trace: host ray batch in, solution left in HBM",
                    "with_hits_d2h": "+ every detector's hit table (the columns the detector keeps) copied to host memory",
-                   "with_last_segment_view": "+ bmo_result_view_select(HITS | LAST_SEGMENT): beam tree, last ray of every beam and hits on the host",
+                   "with_last_segment_view": "+ bmo_result_view_select(LAST_SEGMENT) + the hit columns: beam tree, last ray of every beam and the detectors' data on the host",
                    "with_full_view": "+ bmo_result_view: the whole segment log on the host (PCIe-bound)"}
     return out
 

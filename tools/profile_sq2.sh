@@ -8,6 +8,6 @@ for set in "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_LDS SQ_
            "SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $O/p$i.err
+  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-extras > /dev/null 2> $O/p$i.err
   python3 tools/pmc_summary.py $O/p$i | tail -2
 done
