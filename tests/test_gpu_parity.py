@@ -416,3 +416,61 @@ def test_hit_columns_and_empty_copies(engine_ok, oracle):
         eng.free_result(res)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("config", ["c4", "c5"])
+def test_full_size_properties_c4_c5(engine_ok, oracle, config):
+    """BASELINE configs 4 (2^18 PolarizedRays, 6 refracting surfaces) and 5 (one GPU's shard: 2^21 Rays, 32 elements) at FULL size
+     through size-independent properties: determinism with and without the segment log, consistent counters, the
+    sharding identity of SURVEY 8e on the hit tables of two contiguous halves, and a strided sample against the oracle (statuses and
+    segment counts bit-exact; records bit-exact for config 5, 1e-10 relative for the polarized config 4)."""
+    if config == "c4":
+        n, (system, _), rtol = 1 << 18, c4_scene(), LIBM_RTOL
+        bundle = c4_bundle(n)
+    else:
+        n, (system, _), rtol = 1 << 21, c5_scene(), 0.0
+        bundle = c5_bundle(n)
+    scene = bmo.CompiledScene(system, bundle.lambdas)
+    eng = bmo.Engine(scene, 0)
+    try:
+        def solve(b, keep_log, view=True):
+            dev = eng.upload(b)
+            res = eng.trace_device(dev, 100, record_segments=keep_log)
+            size = eng.result_size(res)
+            v = eng.result_view(res, 1) if view else None  # node tables + hits, never the multi-GB log
+            eng.free_result(res)
+            eng.free_batch(dev)
+            return size, v
+
+        size_a, a = solve(bundle, True)
+        size_b, b = solve(bundle, False)
+        assert size_a == size_b
+        calls, nrec, nnodes, nhits = size_a
+        assert int(a.node_nseg.astype(np.int64).sum()) == nrec and nnodes == a.n_nodes and nhits == int(a.det_count.sum())
+        for name in ("node_root", "node_parent", "node_first_child", "node_nseg", "node_status", "det_count", "det_node"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        assert np.array_equal(a.det_data, b.det_data)
+        if config == "c4":
+            assert nnodes == n and int(a.node_nseg.max()) == 7 and nhits == 0  # no splitter, no detector: 7 segments, then the end stop
+        else:
+            assert nnodes > n and nhits > n  # the middle train splits at the beamsplitter; most rays reach a detector
+        half = n // 2
+        parts = [solve(bmo.RayBundle(bundle.kind, bundle.planes[:, lo:lo + half]), False) for lo in (0, half)]
+        assert sum(p[0][0] for p in parts) == calls and sum(p[0][1] for p in parts) == nrec and sum(p[0][2] for p in parts) == nnodes
+        for slot in range(len(scene.detectors)):
+            assert np.array_equal(np.concatenate([p[1].detector_hits(slot) for p in parts]), a.detector_hits(slot)), slot
+        # strided sample against the oracle: its own small solve with the full records
+        step = n // 512
+        idx = np.arange(0, n, step)
+        sample = bmo.RayBundle(bundle.kind, bundle.planes[:, idx])
+        ref = oracle.trace(scene, sample, 100, threads=16)
+        got = eng.trace(sample, 100)
+        compare(got, ref, rtol, config + " sample")
+        pick = np.isin(a.node_root, idx)
+        assert np.array_equal(a.node_nseg[pick], ref.node_nseg) and np.array_equal(a.node_status[pick], ref.node_status)
+        for slot in range(len(scene.detectors)):
+            lo, cnt = int(a.det_offset[slot]), int(a.det_count[slot])
+            roots_of_hits = a.node_root[a.det_node[lo:lo + cnt]]
+            assert np.array_equal(a.detector_hits(slot)[np.isin(roots_of_hits, idx)], ref.detector_hits(slot)), slot
+    finally:
+        eng.close()
