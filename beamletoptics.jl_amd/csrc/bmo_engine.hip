@@ -1240,7 +1240,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
 
     const int nsub = KIND == BMO_BEAM_GAUSSIAN ? 3 : 1;
     // node arrays: roots + room for children (grown on demand)
-    int64_t node_cap = has_split ? 3 * n + 64 : n;
+    // Children need node slots, and every launch must have room for two per record it traces (any record may split).  One splitter per
+    // ray (3 n beams) then asks for 7 n slots before the launch that follows the split; growing the tables there costs a device copy of
+    // every node array (0.3 ms of a 6 ms solve of config C2), so moderate batches get that room up front.  Larger ones grow on demand.
+    int64_t node_cap = has_split ? (n <= ((int64_t)1 << 22) ? 7 * n + 64 : 3 * n + 64) : n;
     auto alloc_nodes = [&](int64_t cap) -> int {
         int r;
         if ((r = R->n_root.alloc(cap * 4))) return r;
@@ -1494,6 +1497,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipEventElapsedTime(&ms, ctxp->step_ev[2 * q], ctxp->step_ev[2 * q + 1]));
         kernel_ms += ms;
         DBG("step %d kernel %.3f ms", q, ms);
+        if (q + 1 < steps && getenv("BMO_GAPS")) {  // diagnosis: device idle time between two step launches (host round trip)
+            float gap = 0;
+            (void)hipEventElapsedTime(&gap, ctxp->step_ev[2 * q + 1], ctxp->step_ev[2 * q + 2]);
+            fprintf(stderr, "[bmo] step %d kernel %.3f ms, gap to the next launch %.3f ms\n", q, ms, gap);
+        }
     }
     lap("steps");
     R->n_nodes = n_nodes;
