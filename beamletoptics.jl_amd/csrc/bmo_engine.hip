@@ -281,8 +281,9 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
 // One launch advances every active beam by up to P.n_fuse bounces.  Bounce 0 reads its records from P.cur; a lane that goes
 // on writes its next record IN PLACE (same slot j) into P.inner[b] and traces it in the same launch — no compaction, no host
 // round trip, the ray stays in registers; lanes that ended leave an invalid record (node = -1) in the inner chunks.  The fused
-// loop ends for a whole workgroup when one of its lanes splits (children need the block-wide slot allocation below) or when none
-// goes on.  Survivors of the last fused bounce and beam-splitter children are compacted into P.nxt as before.
+// loop ends for a WAVE when one of its lanes splits (children need the slot allocation below) or when none goes on; the four waves
+// of a workgroup run their loops independently and meet at the block-wide allocation.  Survivors of the last fused bounce and
+// beam-splitter children are compacted into P.nxt as before.
 template <int KIND, bool LDS, bool ASPH, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -429,10 +430,11 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 }
             }
         }
-        // block-uniform decisions (every thread of the workgroup reaches these barriers)
         bool go_on = b + 1 < P.n_fuse;
-        if (go_on) go_on = !__syncthreads_or(split ? 1 : 0);
-        if (go_on) go_on = __syncthreads_or(survive ? 1 : 0) != 0;
+        // wave-uniform decisions: every wave runs its own fused loop (no workgroup barrier per level: the four waves of a workgroup used to
+        // wait for the slowest of them at every bounce); the workgroup meets again at block_alloc below
+        if (go_on) go_on = !__any(split ? 1 : 0);
+        if (go_on) go_on = __any(survive ? 1 : 0) != 0;
         if (go_on) {
             // go on in place: the next record of a surviving lane is written to the same slot of the next inner chunk
             const Chunk N = P.inner[b];
