@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "bmo_lane.hpp"
@@ -73,7 +74,7 @@ struct BlobHeader {
 
 template <class CharPtr>
 __host__ __device__ inline SceneView view_of(CharPtr blob) {
-    auto h = (const BMO_AS BlobHeader*)(blob);
+    auto h = (const BlobHeader*)(blob);
     SceneView S;
     S.objects = (CObject*)(blob + h->off_objects);
     S.shapes = (CShape*)(blob + h->off_shapes);
@@ -268,13 +269,9 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
         uint4* dst = reinterpret_cast<uint4*>(lds);
         for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
         __syncthreads();
-#if defined(BMO_SCALAR_SCENE)
-        return view_of((const BMO_AS char*)P.blob);  // not instantiated at run time in this build (use_lds is forced off)
-#else
         return view_of((const char*)lds);
-#endif
     } else {
-        return view_of((const BMO_AS char*)P.blob);
+        return view_of((const char*)P.blob);
     }
 }
 
@@ -1383,11 +1380,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     lap("setup");
     const uint32_t blob_bytes = (uint32_t)scene->blob.size();
-#if defined(BMO_SCALAR_SCENE)
-    const int use_lds = 0;  // scene tables are read with scalar loads through the constant address space
-#else
     const int use_lds = (blob_bytes <= 120 * 1024 && !getenv("BMO_NO_LDS")) ? 1 : 0;
-#endif
     DBG("roots initialised n=%lld blob=%u use_lds=%d", (long long)n, blob_bytes, use_lds);
     if (dbg_on()) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1787,6 +1780,25 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
             sh->flags |= BMO_SHAPE_FLAG_CONSECUTIVE;
             sh->tri_begin = d->children[sh->child_begin];
         }
+    }
+    {   // shape classes (bmo_lane.hpp "wave-uniform control flow"): equal class <=> same code path with different numbers
+        bmo_shape* shp = reinterpret_cast<bmo_shape*>(sc->blob.data() + h.off_shapes);
+        std::map<std::vector<int32_t>, int32_t> ids;
+        std::vector<int32_t> cls((size_t)d->n_shapes, 0);
+        auto pass = [&](auto&& wanted) {
+            for (int i = 0; i < d->n_shapes; ++i) {
+                const bmo_shape& sh = shp[i];
+                if (!wanted(sh.kind)) continue;
+                std::vector<int32_t> sig{sh.kind, sh.flags & ((1 << BMO_SHAPE_CLASS_SHIFT) - 1), sh.kind == BMO_SHAPE_MESH ? sh.tri_count : sh.child_count};
+                if (sh.kind == BMO_SHAPE_UNION || sh.kind == BMO_SHAPE_MENISCUS)
+                    for (int c = 0; c < sh.child_count; ++c) sig.push_back(cls[(size_t)d->children[sh.child_begin + c]]);
+                cls[(size_t)i] = ids.emplace(sig, (int32_t)ids.size()).first->second;
+            }
+        };
+        pass([](int k) { return k != BMO_SHAPE_UNION && k != BMO_SHAPE_MENISCUS; });  // leaves first: a meniscus has leaf children,
+        pass([](int k) { return k == BMO_SHAPE_MENISCUS; });                            // a union leaf or meniscus children
+        pass([](int k) { return k == BMO_SHAPE_UNION; });
+        for (int i = 0; i < d->n_shapes; ++i) shp[i].flags = (shp[i].flags & ((1 << BMO_SHAPE_CLASS_SHIFT) - 1)) | (cls[(size_t)i] << BMO_SHAPE_CLASS_SHIFT);
     }
     if (d->n_children) std::memcpy(sc->blob.data() + h.off_children, d->children, 4 * (size_t)d->n_children);
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);

@@ -44,39 +44,31 @@ namespace bmo {
 inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0, g_emu_normal = 0, g_emu_normal_fd = 0;
 #endif
 
-// Scene tables can be addressed through the constant address space (scalar loads, operands in SGPRs) when the build
-// defines BMO_SCALAR_SCENE; otherwise they are plain (generic / LDS) pointers.
-#if defined(__HIPCC__) && defined(BMO_SCALAR_SCENE)
-#define BMO_AS __attribute__((address_space(4)))
-#else
-#define BMO_AS
-#endif
-// BMO_UNIFORM(i): an index that is the same in every active lane by construction (loop counters of loops whose trip count
-// comes from a wave-uniform table entry); tells the compiler so, which keeps the dependent table reads scalar.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
+// Wave-uniform control flow (device builds; -DBMO_DIVERGENT_CTRL restores per-lane control flow for A/B runs).
+// The engine gives every shape a CLASS (bits 8.. of its copy of `flags`): two shapes are of one class when they have the same kind,
+// flags and child / triangle / coefficient count and their children are pairwise of one class — i.e. when evaluating them runs
+// the same code with different numbers.  The lanes of a wave visit the shapes of one class together ("waterfall": one pass per
+// distinct class among the active lanes, tracing_step / normal_any), so inside a pass everything that steers control flow — kinds,
+// counts, flags — has the same value in every active lane although the table entries (positions, radii, ...) stay per lane.
+// BMO_UNIFORM(x) marks such a value: the compiler then branches on it with scalar compares instead of building execution masks
+// for every `switch (kind)` (the leaf switches are most of the kernel's control flow).  Host builds: the identity.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BMO_DIVERGENT_CTRL)
 #define BMO_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
+#define BMO_WATERFALL 1
 #else
 #define BMO_UNIFORM(i) (i)
 #endif
+#define BMO_SHAPE_CLASS_SHIFT 8  // engine-private bits of bmo_shape.flags in the device copy of the scene
 // BMO_WAVE_ALL(p): true when p holds in every lane of the wave that executes this statement (host: the lane itself)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BMO_WAVE_ALL(p) (__all(p) != 0)
 #else
 #define BMO_WAVE_ALL(p) (p)
 #endif
-typedef const BMO_AS bmo_shape CShape;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
-static __device__ __forceinline__ CShape* uniform_shape_ptr(CShape* p) {  // same contract as BMO_UNIFORM, for a table entry
-    const uint64_t a = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return (CShape*)(((uint64_t)hi << 32) | lo);
-}
-#else
-static BMO_HD CShape* uniform_shape_ptr(CShape* p) { return p; }
-#endif
-typedef const BMO_AS bmo_object CObject;
-typedef const BMO_AS double CDouble;
-typedef const BMO_AS int32_t CInt;
+typedef const bmo_shape CShape;
+typedef const bmo_object CObject;
+typedef const double CDouble;
+typedef const int32_t CInt;
 
 
 struct SceneView {
@@ -379,7 +371,7 @@ template <class T, bool ASPH>
 BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
     // every table read of this leaf in one batch (the reads are LDS / scalar-cache round trips of ~100 cycles each: issued one by
     // one at their points of use they, not the arithmetic, set the pace of the march)
-    const int kind = s.kind;
+    const int kind = BMO_UNIFORM(s.kind);
     const double P0 = s.p[0], P1 = s.p[1], P2 = s.p[2], P3 = s.p[3];
     v3<T> p = to_local(s, pt);
     if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
@@ -488,7 +480,7 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
 // leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
 template <class T, bool ASPH>
 BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
-    const bool men = s.kind == BMO_SHAPE_MENISCUS;
+    const bool men = BMO_UNIFORM(s.kind) == BMO_SHAPE_MENISCUS;
     v3<T> p = pt;
     if (men) p = to_local(s, pt);
     const int nleaf = men ? 3 : 1;
@@ -509,86 +501,119 @@ BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
 // v[c * stride] holds a lower bound of child c's sdf at the point of the previous evaluation (-inf = unknown).
 constexpr int BMO_CC_MAX = 8;
 struct ChildCache {
-    double* v;
+    double* v;      // v[c * stride]: lower bound of child c's sdf at the point where `acc` was last zero (-inf = unknown)
     int stride;
     int prev_best;  // arg-min child of the previous evaluation (evaluated first: it usually gives the tightest bound)
+    double others_lb = -__builtin_huge_val();  // min of v[c] over the children other than prev_best (-inf: some child has no usable bound)
+    double acc = 0.0;                          // upper bound of the distance the evaluation point has moved since the v[] were stored
+    bool valid = false;                        // v[] belongs to the current march (false until its first evaluation has stored every child)
 };
 BMO_HD void child_cache_reset(ChildCache& cc) {
-    for (int c = 0; c < BMO_CC_MAX; ++c) cc.v[c * cc.stride] = -kinf();
     cc.prev_best = 0;
+    cc.others_lb = -kinf();  // the first evaluation of a march looks at every child and stores its value
+    cc.acc = 0.0;
+    cc.valid = false;
 }
 
 // sdf(shape, p) for any SDF shape incl. UnionSDF (UnionSDF.jl:53-56, left-fold min) together with
 // the first-minimum child (argmin of UnionSDF.jl:86-91; same ordering rule as Base.min).
 //
 // Children that provably cannot be the minimum are not evaluated (result-preserving, DESIGN.md "union child skip"):
-//  (1) bounding sphere: outside its inflated bounding sphere a child's sdf is >= |p-c| - R + 1e-6;
-//  (2) Lipschitz memory: every exact child sdf is 1-Lipschitz, so after the march moved the point by `moved` the child's value is
-//      >= (its value, or lower bound, at the previous point) - moved.
+//  Lipschitz memory: every exact child sdf is 1-Lipschitz, so after the march moved the point by `moved` the child's value is
+//  >= (its value, or lower bound, at the previous point) - moved.  (Round 1 also tested each child's bounding sphere per evaluation;
+//  that test cost more than it saved — profiles/r02_ab_child_skip_variants.txt — and is gone.)
 // A child whose lower bound exceeds max(bound, 0) by a margin is strictly greater than the final minimum (bound >= final minimum),
 // so it changes neither the fold min nor the first-minimum index.  Evaluation order: the previous arg-min child first, then index
 // order; min is exact and the arg-min rule below is written order-independently (lowest index among equal minima, -0.0 < +0.0
 // like isless), so the result equals the reference's left fold.
+// The usual iteration of a march — the previous arg-min child still wins and every other child is out of reach — is decided with ONE
+// compare: `others_lb` is the smallest stored bound among the other children, so `others_lb - acc > bound` implies each child's own
+// test; the stored values are then left alone and only `acc`, the distance moved since they were stored, grows.  Otherwise every
+// child is looked at (evaluated, or its bound re-based to this point), which zeroes `acc` again.
 template <bool ASPH>
 BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child, ChildCache& cc, double moved) {
 #if defined(BMO_EMU_STATS)
     ++g_emu_sdf_any;
 #endif
     const v3<double> pt{p.x, p.y, p.z};
-    const bool uni = s.kind == BMO_SHAPE_UNION;
-    const int nch = uni ? s.child_count : 1;
+    const bool uni = BMO_UNIFORM(s.kind) == BMO_SHAPE_UNION;
+    const int nch = uni ? BMO_UNIFORM(s.child_count) : 1;
     double best = kinf();
     best_child = 0;
     bool have = false;
-    const int first = (uni && cc.prev_best < nch) ? cc.prev_best : 0;
-    const double slack = moved * (1.0 + 1e-9) + 1e-12;  // |dir| is 1 only to rounding
+    // the child evaluated first: this lane's previous arg-min; where the shape tables are read wave-uniformly, the first active
+    // lane's (any order gives the same result, see above; a coherent wave mostly agrees on it)
+    const int first = (uni && BMO_UNIFORM(cc.prev_best) < nch) ? BMO_UNIFORM(cc.prev_best) : 0;
+    const double acc = cc.acc + (moved * (1.0 + 1e-9) + 1e-12);  // |dir| is 1 only to rounding
     // children stored back to back in the shape table (the usual case; flagged by the engine when it copies the scene): child c is
     // shape first_id + c, no look-up in children[]
-    const bool consecutive = uni && (s.flags & BMO_SHAPE_FLAG_CONSECUTIVE);
+    const int32_t sflags = BMO_UNIFORM(s.flags);
+    const bool consecutive = uni && (sflags & BMO_SHAPE_FLAG_CONSECUTIVE);
     const int32_t cb = s.child_begin, first_id = s.tri_begin;
-    const bool all_exact = !(s.flags & BMO_SHAPE_FLAG_INEXACT);
+    const bool all_exact = !(sflags & BMO_SHAPE_FLAG_INEXACT);
+    double m1 = kinf(), m2 = kinf();  // the two smallest bounds stored by this evaluation, and whose the smallest is
+    int i1 = -1;
     BMO_NOUNROLL
     for (int q = 0; q < nch; ++q) {
         const int c = q == 0 ? first : (q <= first ? q - 1 : q);
-        CShape& ch = *uniform_shape_ptr(uni ? &S.shapes[consecutive ? first_id + BMO_UNIFORM(c) : S.children[cb + BMO_UNIFORM(c)]] : &s);
-        const double cached = (uni && c < BMO_CC_MAX) ? cc.v[c * cc.stride] : -kinf();
+        CShape& ch = uni ? S.shapes[consecutive ? first_id + c : S.children[cb + c]] : s;
         bool skip = false;
         double lb = -kinf();
         // a union is flagged INEXACT when one of its children is (scene compiler): only then the child's own flag is looked up
-        if (have && c < BMO_CC_MAX && (all_exact || !(ch.flags & BMO_SHAPE_FLAG_INEXACT))) {
+        const bool usable = uni && c < BMO_CC_MAX && (all_exact || !(BMO_UNIFORM(ch.flags) & BMO_SHAPE_FLAG_INEXACT));
+        if (have && usable && cc.valid) {
             const double bound = best > 0.0 ? best : 0.0;
-            lb = cached - slack;
+            lb = cc.v[c * cc.stride] - acc;
             skip = lb > bound + 1e-12;
         }
+        double stored = lb;
         if (!skip) {
 #if defined(BMO_EMU_STATS)
             ++g_emu_sdf_leaf;
 #endif
             const double v = sdf_simple<double, ASPH>(S, ch, pt);
-            if (uni && c < BMO_CC_MAX) cc.v[c * cc.stride] = v;
+            stored = v;
             if (!have) {
                 best = v;
                 best_child = c;
                 have = true;
+                if (uni && first == cc.prev_best) {  // all the others out of reach?
+                    const double bound = v > 0.0 ? v : 0.0;
+                    if (cc.others_lb - acc > bound + 1e-12) {
+                        cc.acc = acc;
+                        return v;  // prev_best, others_lb and the stored values stay as they are
+                    }
+                }
             } else {
                 const bool less = (v < best) || (v == best && sgn(v) && !sgn(best));
                 const bool same = (v == best) && (sgn(v) == sgn(best));
                 if (less || (same && c < best_child)) best_child = c;
                 best = jmin(best, v);
             }
-        } else if (uni && c < BMO_CC_MAX) {
-            cc.v[c * cc.stride] = lb;  // still a valid lower bound at this point
+        }
+        if (uni && c < BMO_CC_MAX) cc.v[c * cc.stride] = stored;  // a value, or a bound that is still valid at this point
+        const double key = (usable && stored == stored) ? stored : -kinf();  // NaN: never skipped, so no bound
+        if (key < m1) {
+            m2 = m1;
+            m1 = key;
+            i1 = c;
+        } else if (key < m2) {
+            m2 = key;
         }
     }
-    if (uni) cc.prev_best = best_child;
+    if (uni) {
+        cc.prev_best = best_child;
+        cc.others_lb = (i1 == best_child) ? m2 : m1;
+        cc.acc = 0.0;
+        cc.valid = true;
+    }
     return best;
 }
 
-// normal3d(shape, p): UnionSDF -> normal of its argmin child (UnionSDF.jl:86-91); otherwise
+// normal3d(shape, p) of a non-union shape (UnionSDF -> normal of its argmin child, UnionSDF.jl:86-91: normal_any below):
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88).
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_child) {
-    CShape& sh = s.kind == BMO_SHAPE_UNION ? S.shapes[S.children[s.child_begin + best_child]] : s;
+BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
     {
 #if defined(BMO_EMU_STATS)
         ++g_emu_normal;
@@ -619,6 +644,27 @@ BMO_HD d3 normal_any(const SceneView& S, CShape& s, const d3& p, int32_t best_ch
         else g2 = minus ? g2 - v : v;
     }
     return normalize_div(d3{g0, g1, g2});
+}
+// normal3d of shape `sid` (table entry `s`) or, for a UnionSDF, of its arg-min child
+template <bool ASPH>
+BMO_HD d3 normal_any(const SceneView& S, int32_t sid, CShape& s, const d3& p, int32_t best_child) {
+    int32_t tid = sid;
+    if (BMO_UNIFORM(s.kind) == BMO_SHAPE_UNION) tid = S.children[s.child_begin + best_child];
+#if defined(BMO_WATERFALL)
+    // one pass per distinct class among the lanes' shapes (the arg-min children of a union may be of different kinds)
+    d3 n{0, 0, 0};
+    const int32_t cls = S.shapes[tid].flags >> BMO_SHAPE_CLASS_SHIFT;
+    for (bool pending = true; pending;) {
+        const int32_t u = __builtin_amdgcn_readfirstlane(cls);
+        if (u == cls) {
+            n = normal_of<ASPH>(S, S.shapes[tid], p);
+            pending = false;
+        }
+    }
+    return n;
+#else
+    return normal_of<ASPH>(S, S.shapes[tid], p);
+#endif
 }
 
 // ------------------------------------------------------------------ miss cull (see file header)
@@ -684,19 +730,20 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         if (t_lb < 0.0) return h;                            // provable `nothing`
         if (t_lb * (1.0 - 1e-9) - 1e-9 > t_limit) return h;  // provable loser of the nearest-hit selection
     }
-    if (s.kind == BMO_SHAPE_MESH) {
+    if (BMO_UNIFORM(s.kind) == BMO_SHAPE_MESH) {
         int fid = -1;
         double t0 = kinf();
+        const int ntri = BMO_UNIFORM(s.tri_count), tri0 = s.tri_begin;
         BMO_NOUNROLL
-        for (int i = 0; i < s.tri_count; ++i) {
-            double t = moeller_trumbore(S.tris + 9 * (s.tri_begin + i), pos0, dir0, S.mt_keps, S.mt_leps);
+        for (int i = 0; i < ntri; ++i) {
+            double t = moeller_trumbore(S.tris + 9 * (tri0 + i), pos0, dir0, S.mt_keps, S.mt_leps);
             if (t < t0) {
                 t0 = t;
                 fid = i;
             }
         }
         if (fid < 0) return h;
-        CDouble* f = S.tris + 9 * (s.tri_begin + fid);
+        CDouble* f = S.tris + 9 * (tri0 + fid);
         d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
         d3 n = normalize_div(cross3(sub3(V2, V1), sub3(V3, V1)));  // normal3d(mesh, fID) Mesh.jl:183-192
         h.t = t0;
@@ -705,7 +752,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         return h;
     }
     enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2 };
-    const bool exact = !(s.flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
+    const bool exact = !(BMO_UNIFORM(s.flags) & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
     int phase = CLASSIFY;
     d3 pos = pos0, dir = dir0;
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
@@ -773,7 +820,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         pending = false;
         // single normal evaluation site: the reference's normal3d, for the start classification on the surface
         // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the hit
-        const d3 n = normal_any<ASPH>(S, s, pos, bc);
+        const d3 n = normal_any<ASPH>(S, sid, s, pos, bc);
         if (phase == CLASSIFY) {
             if (dot3(dir, n) <= 0) {  // entering
                 phase = INSIDE;
@@ -838,11 +885,11 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
             int kind = BMO_OBJ_INTERSECTABLE, np = 1;
             int32_t sh0 = hs, sh1 = -1, sh2 = -1;
             if (o >= 0) {
-                CObject& ob = S.objects[o];
-                kind = ob.kind;
-                sh0 = ob.shape[0];
-                sh1 = ob.shape[1];
-                sh2 = ob.shape[2];
+                CObject& ob = S.objects[BMO_UNIFORM(o)];
+                kind = BMO_UNIFORM(ob.kind);
+                sh0 = BMO_UNIFORM(ob.shape[0]);
+                sh1 = BMO_UNIFORM(ob.shape[1]);
+                sh2 = BMO_UNIFORM(ob.shape[2]);
                 np = (kind == BMO_OBJ_DOUBLET) ? 2 : (kind == BMO_OBJ_CUBE_BS ? 3 : (kind == BMO_OBJ_PLATE_BS ? 2 : 1));
                 if (kind == BMO_OBJ_NONINTERACTABLE) np = 0;
                 if (kind == BMO_OBJ_PLATE_BS) {  // coating first, then substrate
@@ -859,16 +906,14 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
                 // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
                 // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
                 if (o >= 0 && sid == tested_shape) continue;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_SCALAR_SCENE)
-                // waterfall: the shape id is made wave-uniform (one pass per distinct id; only the hinted slot can differ
-                // between lanes), so every table read inside becomes a scalar load.
+#if defined(BMO_WATERFALL)
+                // one pass per distinct shape class (only the hinted slot can differ between lanes): see BMO_UNIFORM
                 Hit tmp = no_hit();
+                const int32_t cls = S.shapes[sid].flags >> BMO_SHAPE_CLASS_SHIFT;
                 for (bool pending = true; pending;) {
-                    const int32_t u = __builtin_amdgcn_readfirstlane(sid);
-                    int32_t u_cmp = u;
-                    asm volatile("" : "+s"(u_cmp));  // keeps the optimiser from substituting the per-lane id back for `u`
-                    if (u_cmp == sid) {
-                        tmp = intersect_shape<ASPH>(S, u, pos, dir, lim, cc);
+                    const int32_t u = __builtin_amdgcn_readfirstlane(cls);
+                    if (u == cls) {
+                        tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim, cc);
                         pending = false;
                     }
                 }
