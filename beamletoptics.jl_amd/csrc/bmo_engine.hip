@@ -1666,6 +1666,30 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     return BMO_OK;
 }
 
+// bmo_selftest: the branch-free forms of bmo_lane.hpp against the rules they stand for, bitwise
+__global__ void selftest_minmax_kernel(const double* __restrict__ v, int n, int32_t* __restrict__ bad) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n * n) return;
+    const double x = v[i / n], y = v[i % n];
+    auto same = [](double a, double b) { return (isnan_(a) && isnan_(b)) || __double_as_longlong(a) == __double_as_longlong(b); };
+    int form = 0;
+    if (!same(jmax(x, y), jmax_rule(x, y))) form = 1;
+    else if (!same(jmin(x, y), jmin_rule(x, y))) form = 2;
+    else {
+        // Dual forms: value as above, partials of the winner (x on ties)
+        const Dual X{x, 1.0, 2.0, 3.0}, Y{y, 5.0, 6.0, 7.0};
+        const Dual mx = jmax(X, Y), mn = jmin(X, Y), mx0 = jmax(X, y), mn0 = jmin(X, y);
+        const bool ywx = (y > x) || (sgn(y) < sgn(x)), ywn = (y < x) || (sgn(y) > sgn(x));
+        if (!same(mx.v, jmax_rule(x, y)) || mx.a != (ywx ? 5.0 : 1.0) || mx.c != (ywx ? 7.0 : 3.0)) form = 3;
+        else if (!same(mn.v, jmin_rule(x, y)) || mn.a != (ywn ? 5.0 : 1.0) || mn.c != (ywn ? 7.0 : 3.0)) form = 4;
+        else if (!same(mx0.v, jmax_rule(x, y)) || mx0.b != (ywx ? 0.0 : 2.0)) form = 5;
+        else if (!same(mn0.v, jmin_rule(x, y)) || mn0.b != (ywn ? 0.0 : 2.0)) form = 6;
+        const Dual ab = jabs(X);
+        if (!form && (!same(ab.v, fabs(x)) || ab.a != (sgn(x) ? -1.0 : 1.0))) form = 7;
+    }
+    if (form && atomicCAS(bad, -1, i) == -1) bad[1] = form;
+}
+
 template <class T>
 int dl(std::vector<T>& h, const void* d, size_t count) {
     h.resize(count);
@@ -1686,6 +1710,27 @@ int bmo_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int bmo_selftest(int32_t device) {
+    if (hipSetDevice(device) != hipSuccess) return fail(BMO_ERR_NO_DEVICE, "hipSetDevice");
+    const double tiny = 4.9406564584124654e-324, big = 1.7976931348623157e308;
+    std::vector<double> v{0.0, -0.0, tiny, -tiny, 2.2250738585072014e-308, -2.2250738585072014e-308, 1.0, -1.0, 1.0000000000000002, 0.5, -0.5, 3.0, -3.0,
+                          big, -big, (double)INFINITY, -(double)INFINITY, (double)NAN, -(double)NAN, 1e-10, -1e-10, 1e-300, 123.456, -123.456};
+    const int n = (int)v.size();
+    DevBuf d_v, d_bad;
+    int rc;
+    if ((rc = d_v.alloc((size_t)n * 8)) || (rc = d_bad.alloc(16))) return rc;
+    HIP_TRY(hipMemcpy(d_v.p, v.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_bad.p, 0xFF, 16));
+    hipLaunchKernelGGL(selftest_minmax_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, 0, (const double*)d_v.p, n, (int32_t*)d_bad.p);
+    HIP_TRY(hipGetLastError());
+    int32_t bad[4];
+    HIP_TRY(hipMemcpy(bad, d_bad.p, 16, hipMemcpyDeviceToHost));
+    if (bad[0] != -1)
+        return fail(BMO_ERR_INTERNAL, "device min/max differs from the rule: form " + std::to_string(bad[1]) + " on (" + std::to_string(v[(size_t)(bad[0] / n)]) + ", " +
+                                          std::to_string(v[(size_t)(bad[0] % n)]) + ")");
+    return BMO_OK;
 }
 
 int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {

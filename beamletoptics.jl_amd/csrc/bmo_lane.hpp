@@ -105,14 +105,32 @@ BMO_HD Hit no_hit() {
 }
 
 // ------------------------------------------------------------------ scalar rules (Julia Base)
-BMO_HD double jmax(double x, double y) {
+// max / min of Base for Float64: NaN if either is NaN, -0.0 < +0.0.  The rule as written:
+BMO_HD double jmax_rule(double x, double y) {
     if (isnan_(x) || isnan_(y)) return x + y;
     return ((y > x) || (sgn(y) < sgn(x))) ? y : x;
 }
-BMO_HD double jmin(double x, double y) {
+BMO_HD double jmin_rule(double x, double y) {
     if (isnan_(x) || isnan_(y)) return x + y;
     return ((y < x) || (sgn(y) > sgn(x))) ? y : x;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_HW_MINMAX)
+// Optional device form (-DBMO_HW_MINMAX): v_max_f64 / v_min_f64 order the zeros the same way (+0 > -0) and return the other operand for
+// a NaN, so one NaN select on top gives the rule without control flow (the rule form compiles to execution-mask branches).  Measured:
+// -1.5 % on config 5, -2 % on the vignetted bundle, +1 % on config 2 (profiles/r02_ab_minmax_forms.txt) — not the default;
+// bmo_selftest compares whichever form is compiled in with the rule, bit for bit on the special values, on the device.
+BMO_HD double jmax(double x, double y) {
+    const double m = __builtin_fmax(x, y);
+    return (isnan_(x) | isnan_(y)) ? x + y : m;
+}
+BMO_HD double jmin(double x, double y) {
+    const double m = __builtin_fmin(x, y);
+    return (isnan_(x) | isnan_(y)) ? x + y : m;
+}
+#else
+BMO_HD double jmax(double x, double y) { return jmax_rule(x, y); }
+BMO_HD double jmin(double x, double y) { return jmin_rule(x, y); }
+#endif
 BMO_HD double jabs(double x) { return fabs(x); }
 BMO_HD double jsqrt(double x) { return sqrt(x); }
 BMO_HD double val(double x) { return x; }
@@ -140,26 +158,29 @@ BMO_HD Dual jsqrt(const Dual& x) {
     double d = 1.0 / (2.0 * s);
     // sqrt(0) with all-zero partials keeps them zero (ForwardDiff's NaN-safe partial scaling; pinned by the reference's narrow
     // point-source KAT, test/runtests.jl:2755-2761 — see oracle/jl_math.hpp)
-    if (!(fabs(d) < kinf()) && x.a == 0 && x.b == 0 && x.c == 0) return {s, x.a, x.b, x.c};
-    return {s, x.a * d, x.b * d, x.c * d};
+    const bool keep = !(fabs(d) < kinf()) && x.a == 0 && x.b == 0 && x.c == 0;  // selects, not a branch
+    return {s, keep ? x.a : x.a * d, keep ? x.b : x.b * d, keep ? x.c : x.c * d};
 }
-BMO_HD Dual jabs(const Dual& x) { return sgn(x.v) ? -x : x; }
+BMO_HD Dual jabs(const Dual& x) {
+    const bool neg = sgn(x.v);
+    return {neg ? -x.v : x.v, neg ? -x.a : x.a, neg ? -x.b : x.b, neg ? -x.c : x.c};
+}
 BMO_HD Dual jmax(const Dual& x, const Dual& y) {
-    bool yw = (y.v > x.v) || (sgn(y.v) < sgn(x.v));
+    bool yw = (y.v > x.v) | (sgn(y.v) < sgn(x.v));
     double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
     return {jmax(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
 }
 BMO_HD Dual jmin(const Dual& x, const Dual& y) {
-    bool yw = (y.v < x.v) || (sgn(y.v) > sgn(x.v));
+    bool yw = (y.v < x.v) | (sgn(y.v) > sgn(x.v));
     double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
     return {jmin(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
 }
 BMO_HD Dual jmax(const Dual& x, double y) {
-    double dx = ((y > x.v) || (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
+    double dx = ((y > x.v) | (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
     return {jmax(x.v, y), x.a * dx, x.b * dx, x.c * dx};
 }
 BMO_HD Dual jmin(const Dual& x, double y) {
-    double dx = ((y < x.v) || (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
+    double dx = ((y < x.v) | (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
     return {jmin(x.v, y), x.a * dx, x.b * dx, x.c * dx};
 }
 

@@ -273,6 +273,13 @@ const char* bmo_last_error(void);
 /* Number of usable HIP devices (0 = none). */
 int bmo_device_count(void);
 
+/* Device self-test of the scalar rules of the lane code as the device compiler built them: Base.max / Base.min for Float64 (NaN if
+   either operand is NaN, -0.0 < +0.0; the AbstractSDF leaf formulas), their ForwardDiff.Dual forms (partials of the winner) and
+   abs(::Dual), written without control flow, against the rule written with compares, bit for bit over every pair of a table of
+   special values (zeros, denormals, infinities, NaN, ordinary numbers).  BMO_OK, or BMO_ERR_INTERNAL with the first mismatch in
+   bmo_last_error(). */
+int bmo_selftest(int32_t device);
+
 int bmo_scene_create(const bmo_scene_desc* desc, bmo_scene** out);
 int bmo_scene_destroy(bmo_scene* scene);
 /* The engine keeps freed device blocks in a per-device pool for reuse by the next trace; this returns them to HIP. */

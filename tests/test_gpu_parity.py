@@ -32,6 +32,13 @@ def run_both(oracle, system, bundle, r_max=100, threads=16):
     return got, ref
 
 
+def test_device_selftest(engine_ok):
+    """The hardware min / max the lane code uses (v_max_f64 / v_min_f64 + NaN select, and the Dual forms) against the rule written with
+    compares (Base.max / Base.min: NaN-propagating, -0.0 < +0.0), bit for bit on the special values."""
+    rc = engine_ok.bmo_selftest(0)
+    assert rc == 0, engine_ok.bmo_last_error().decode()
+
+
 def test_c1_bit_exact(engine_ok, oracle):
     system, _ = c1_scene()
     got, ref = run_both(oracle, system, c1_bundle(1000))
