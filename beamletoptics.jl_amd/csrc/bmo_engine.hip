@@ -160,7 +160,10 @@ struct OldSolution {
     const double* aux;           // Gaussian: [node][4] = l0, w0, Re E0, Im E0
 };
 
-constexpr int MAX_FUSE = 16;
+#if !defined(BMO_MAX_FUSE)
+#define BMO_MAX_FUSE 32
+#endif
+constexpr int MAX_FUSE = BMO_MAX_FUSE;
 struct StepParams {
     const char* blob;
     uint32_t blob_bytes;
@@ -844,20 +847,40 @@ __global__ void hit_offsets_kernel(const int32_t* __restrict__ offs, const int32
     if (d < n_det) out[d] = offs[(int64_t)d * n];
     if (d == n_det) out[d] = offs[(int64_t)n_det * n - 1] + flags[(int64_t)n_det * n - 1];
 }
-// one thread per (node, double of its hit record): the 72-byte records are read and written as contiguous runs
-__global__ void hit_gather_kernel(const int32_t* order, const int32_t* hit_det, const double* hit, int64_t n, int32_t nsub,
-                                  const int32_t* offs, double* out, int32_t* out_node) {
+// A workgroup takes 256 consecutive canonical nodes: their (id, destination) pairs go to LDS once, then the 72-byte records are copied
+// as contiguous runs, one double per thread and turn (the first form of this kernel re-read the three index tables for each of
+// the 9 doubles: 152 us per C2 solve for 0.3 GB of traffic).
+__global__ void hit_gather_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ hit_det, const double* __restrict__ hit, int64_t n, int32_t nsub,
+                                  const int32_t* __restrict__ offs, int64_t cap, double* __restrict__ out, int32_t* __restrict__ out_node,
+                                  unsigned long long* __restrict__ overflow) {
+    __shared__ int32_t s_nd[256], s_pos[256];
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    {
+        const int64_t i = i0 + threadIdx.x;
+        int32_t nd = -1, pos = -1;
+        if (i < n) {
+            nd = order[i];
+            const int32_t d = hit_det[nd];
+            if (d >= 0) {
+                pos = offs[(int64_t)d * n + i];
+                if ((int64_t)pos + nsub > cap) {
+                    atomicAdd(overflow, 1ull);
+                    pos = -1;
+                } else {
+                    for (int q = 0; q < nsub; ++q) out_node[pos + q] = (int32_t)i;
+                }
+            }
+        }
+        s_nd[threadIdx.x] = nd;
+        s_pos[threadIdx.x] = pos;
+    }
+    __syncthreads();
     const int width = 9 * nsub;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = t / width;
-    if (i >= n) return;
-    const int k = (int)(t - i * width);
-    const int32_t nd = order[i];
-    const int32_t d = hit_det[nd];
-    if (d < 0) return;
-    const int64_t pos = offs[(int64_t)d * n + i];
-    out[pos * 9 + k] = hit[(int64_t)nd * width + k];
-    if (k % 9 == 0) out_node[pos + k / 9] = (int32_t)i;
+    for (int t = threadIdx.x; t < 256 * width; t += 256) {
+        const int e = t / width, k = t - e * width;
+        const int32_t pos = s_pos[e];
+        if (pos >= 0) out[(int64_t)pos * 9 + k] = hit[(int64_t)s_nd[e] * width + k];
+    }
 }
 
 // Node tables in the ABI's canonical order, built on the device (the host used to loop over 3 M nodes per C2 solve):
@@ -1422,13 +1445,17 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // launch.  BMO_FUSE=1 restores one launch per bounce level.
     int fuse_max = 1;
     if (KIND != BMO_BEAM_GAUSSIAN) {
-        fuse_max = MAX_FUSE;  // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by another 1-3 %
+        // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by
+        // another 1-3 %, and 32 beat 16 by 1-2.5 % (config C2 reaches its splitter, level 17, in the first launch: 2 launches instead of 3)
+        fuse_max = MAX_FUSE;
         if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(MAX_FUSE, atoi(e)));
     }
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
     while (cur.count > 0) {
         const int64_t m = cur.count;
-        const int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
+        int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
+        // the in-place levels of a launch are allocated up front: at most 24 GB of them (2^24 beams: 8 levels)
+        if (keep_log) n_fuse = (int)std::min<int64_t>(n_fuse, 1 + (int64_t)(((size_t)24 << 30) / ((size_t)std::max<int64_t>(m, 1) * rec_bytes)));
         Chunk nxt, inner[MAX_FUSE - 1];
         for (int q = 0; q + 1 < n_fuse; ++q) {
             if (!keep_log && q > 0) {
@@ -1500,29 +1527,35 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     lap("steps");
     R->n_nodes = n_nodes;
-    {
-        std::vector<unsigned long long> sh(64 * 16);
-        HIP_TRY(hipMemcpyAsync(sh.data(), shard_buf.p, 64 * 128, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long tot = 0;
-        for (int q = 0; q < 64; ++q) tot += sh[(size_t)q * 16];
-        R->calls = tot;
-    }
     R->n_steps = steps;
     R->kernel_ms = kernel_ms;
-    {   // segments = sum of the beams' segment counts (chunk counts include the holes of fused levels)
-        DevBuf d_sum, tmp;
+    // Everything below is queued behind ONE synchronisation at the end: temporaries stay alive until then (`keep`: a block that went
+    // back to the pool could be handed to a view running on another stream), counts are read back last.
+    std::vector<std::unique_ptr<DevBuf>> keep;
+    auto temp = [&](size_t bytes) -> DevBuf* {
+        auto b = std::make_unique<DevBuf>();
+        if (b->alloc(bytes)) return nullptr;
+        keep.push_back(std::move(b));
+        return keep.back().get();
+    };
+    // pinned read-back area: [0..1023] call-counter shards (64 x 16 words), [1024] segment count, [1025..] hit offsets
+    static_assert(sizeof(unsigned long long) == 8, "");
+    HostBuf h_tail;
+    if ((rc = h_tail.alloc((1024 + 1 + 1025) * 8))) return rc;
+    unsigned long long* const h_sh = static_cast<unsigned long long*>(h_tail.p);
+    long long* const h_sum = reinterpret_cast<long long*>(h_sh + 1024);
+    int32_t* const h_off = reinterpret_cast<int32_t*>(h_sh + 1025);
+    *h_sum = 0;
+    HIP_TRY(hipMemcpyAsync(h_sh, shard_buf.p, 64 * 128, hipMemcpyDeviceToHost, stream));
+    if (n_nodes > 0) {  // segments = sum of the beams' segment counts (chunk counts include the holes of fused levels)
+        DevBuf* d_sum = temp(8);
+        if (!d_sum) return BMO_ERR_OOM;
         size_t tmp_bytes = 0;
-        long long h_sum = 0;
-        if (n_nodes > 0) {
-            if ((rc = d_sum.alloc(8))) return rc;
-            HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum.p, (int)n_nodes, stream));
-            if ((rc = tmp.alloc(tmp_bytes))) return rc;
-            HIP_TRY(hipcub::DeviceReduce::Sum(tmp.p, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum.p, (int)n_nodes, stream));
-            HIP_TRY(hipMemcpyAsync(&h_sum, d_sum.p, 8, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-        R->n_records = (int64_t)h_sum;
+        HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum->p, (int)n_nodes, stream));
+        DevBuf* tmp = temp(tmp_bytes);
+        if (!tmp) return BMO_ERR_OOM;
+        HIP_TRY(hipcub::DeviceReduce::Sum(tmp->p, tmp_bytes, (const int32_t*)R->n_nseg.p, (long long*)d_sum->p, (int)n_nodes, stream));
+        HIP_TRY(hipMemcpyAsync(h_sum, d_sum->p, 8, hipMemcpyDeviceToHost, stream));
     }
 
     // ---- canonical node order (bundle order x BFS order): sort by (root, depth, path)
@@ -1542,25 +1575,28 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             const int bits_path = (int)h_ctr.max_depth;  // one bit per level
             const int bits = bits_root + bits_depth + bits_path;
             const bool narrow = bits <= 32;
-            if ((rc = keys_in.alloc((size_t)n_nodes * (narrow ? 4 : 8))) || (rc = keys_out.alloc((size_t)n_nodes * (narrow ? 4 : 8))) ||
-                (rc = vals_out.alloc((size_t)n_nodes * 4)))
-                return rc;
+            DevBuf *k_in = temp((size_t)n_nodes * (narrow ? 4 : 8)), *k_out = temp((size_t)n_nodes * (narrow ? 4 : 8)), *v_out = temp((size_t)n_nodes * 4);
+            if (!k_in || !k_out || !v_out) return BMO_ERR_OOM;
             hipLaunchKernelGGL(pack_keys_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes, bits_depth,
-                               bits_path, narrow ? (uint32_t*)keys_in.p : nullptr, narrow ? nullptr : (unsigned long long*)keys_in.p);
+                               bits_path, narrow ? (uint32_t*)k_in->p : nullptr, narrow ? nullptr : (unsigned long long*)k_in->p);
             size_t tmp_bytes = 0;
             if (narrow) {
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
-                                                           (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
-                if ((rc = tmp.alloc(tmp_bytes))) return rc;
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)keys_in.p, (uint32_t*)keys_out.p, (const int32_t*)R->order.p,
-                                                           (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)k_in->p, (uint32_t*)k_out->p, (const int32_t*)R->order.p,
+                                                           (int32_t*)v_out->p, (int)n_nodes, 0, bits, stream));
+                DevBuf* st = temp(tmp_bytes);
+                if (!st) return BMO_ERR_OOM;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(st->p, tmp_bytes, (const uint32_t*)k_in->p, (uint32_t*)k_out->p, (const int32_t*)R->order.p,
+                                                           (int32_t*)v_out->p, (int)n_nodes, 0, bits, stream));
             } else {
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
-                                                           (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
-                if ((rc = tmp.alloc(tmp_bytes))) return rc;
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const unsigned long long*)keys_in.p, (unsigned long long*)keys_out.p,
-                                                           (const int32_t*)R->order.p, (int32_t*)vals_out.p, (int)n_nodes, 0, bits, stream));
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)k_in->p, (unsigned long long*)k_out->p,
+                                                           (const int32_t*)R->order.p, (int32_t*)v_out->p, (int)n_nodes, 0, bits, stream));
+                DevBuf* st = temp(tmp_bytes);
+                if (!st) return BMO_ERR_OOM;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(st->p, tmp_bytes, (const unsigned long long*)k_in->p, (unsigned long long*)k_out->p,
+                                                           (const int32_t*)R->order.p, (int32_t*)v_out->p, (int)n_nodes, 0, bits, stream));
             }
+            std::swap(R->order.p, v_out->p);  // the sorted ids are the order; the iota goes to `keep`
+            std::swap(R->order.bytes, v_out->bytes);
         } else {
             // deep trees: ranks within each tree level, level by level, then sort by (root, depth, rank)
             const int64_t md = (int64_t)h_ctr.max_depth;
@@ -1615,51 +1651,57 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
                                                        (int32_t*)vals_out.p, (int)n_nodes, 0, bits_root + bits_depth, stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(stream));  // the level tables go back to the pool
+            std::swap(R->order.p, vals_out.p);
+            std::swap(R->order.bytes, vals_out.bytes);
         }
-        HIP_TRY(hipStreamSynchronize(stream));
-        std::swap(R->order.p, vals_out.p);
-        std::swap(R->order.bytes, vals_out.bytes);
     }
     lap("order");
     // ---- detector hits in reference push! order: flags -> exclusive scan -> gather
     const int nd = R->n_detectors;
     R->det_count.assign(nd, 0);
     R->det_offset.assign(nd, 0);
-    if (nd > 0 && n_nodes > 0) {
-        DevBuf flags, offs, tmp;
+    const bool with_hits = nd > 0 && n_nodes > 0;
+    if (with_hits) {
         const int64_t tot = (int64_t)nd * n_nodes;
         if (tot >= ((int64_t)1 << 31)) return fail(BMO_ERR_UNSUPPORTED, "detectors x beams exceeds 2^31: split the batch");
-        if ((rc = flags.alloc((size_t)tot * 4)) || (rc = offs.alloc((size_t)tot * 4))) return rc;
-        hipLaunchKernelGGL(hit_flags_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p, n_nodes, nd,
-                           nsub, (int32_t*)flags.p);
-        size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
-        if ((rc = tmp.alloc(tmp_bytes))) return rc;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (const int32_t*)flags.p, (int32_t*)offs.p, (int)tot, stream));
-        // per-detector offsets = scan value at the start of each detector's segment; total = last offs + last flag
         if (nd + 1 > 1024) return fail(BMO_ERR_UNSUPPORTED, "more than 1023 detectors");
-        DevBuf d_off;
-        if ((rc = d_off.alloc((size_t)(nd + 1) * 4))) return rc;
-        hipLaunchKernelGGL(hit_offsets_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)offs.p, (const int32_t*)flags.p, n_nodes, nd, (int32_t*)d_off.p);
-        std::vector<int32_t> h_off(nd + 1, 0);
-        HIP_TRY(hipMemcpyAsync(h_off.data(), d_off.p, (size_t)(nd + 1) * 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        const int64_t total = h_off[nd];
+        DevBuf *flags = temp((size_t)tot * 4), *offs = temp((size_t)tot * 4), *d_off = temp((size_t)(nd + 1) * 4);
+        if (!flags || !offs || !d_off) return BMO_ERR_OOM;
+        hipLaunchKernelGGL(hit_flags_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p, n_nodes, nd,
+                           nsub, (int32_t*)flags->p);
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)flags->p, (int32_t*)offs->p, (int)tot, stream));
+        DevBuf* st = temp(tmp_bytes);
+        if (!st) return BMO_ERR_OOM;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(st->p, tmp_bytes, (const int32_t*)flags->p, (int32_t*)offs->p, (int)tot, stream));
+        // per-detector offsets = scan value at the start of each detector's segment; total = last offs + last flag
+        hipLaunchKernelGGL(hit_offsets_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)offs->p, (const int32_t*)flags->p, n_nodes, nd, (int32_t*)d_off->p);
+        HIP_TRY(hipMemcpyAsync(h_off, d_off->p, (size_t)(nd + 1) * 4, hipMemcpyDeviceToHost, stream));
+        // the hit table is sized before the counts are back on the host: a beam with a hit has ended and every splitting beam has two
+        // children, so there are at most (beams + roots) / 2 of them
+        const int64_t bound = (n_nodes + n) / 2 * nsub + nsub;
+        if ((rc = R->det_data.alloc((size_t)std::max<int64_t>(bound, 1) * 72)) || (rc = R->det_node.alloc((size_t)std::max<int64_t>(bound, 1) * 4))) return rc;
+        hipLaunchKernelGGL(hit_gather_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
+                           (const double*)R->n_hit.p, n_nodes, nsub, (const int32_t*)offs->p, bound, (double*)R->det_data.p, (int32_t*)R->det_node.p,
+                           &d_ctr->overflow);
+    }
+    HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ev_t1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    lap("hits");
+    if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "hit table overflow (internal capacity bound violated)");
+    {
+        unsigned long long tot = 0;
+        for (int q = 0; q < 64; ++q) tot += h_sh[(size_t)q * 16];
+        R->calls = tot;
+        R->n_records = (int64_t)*h_sum;
+    }
+    if (with_hits)
         for (int d = 0; d < nd; ++d) {
             R->det_offset[d] = h_off[d];
             R->det_count[d] = h_off[d + 1] - h_off[d];
         }
-        if ((rc = R->det_data.alloc((size_t)std::max<int64_t>(total, 1) * 72)) || (rc = R->det_node.alloc((size_t)std::max<int64_t>(total, 1) * 4)))
-            return rc;
-        const int64_t gather_threads = n_nodes * 9 * nsub;
-        hipLaunchKernelGGL(hit_gather_kernel, dim3((unsigned)((gather_threads + 255) / 256)), dim3(256), 0, stream, (const int32_t*)R->order.p, (const int32_t*)R->n_hitdet.p,
-                           (const double*)R->n_hit.p, n_nodes, nsub, (const int32_t*)offs.p, (double*)R->det_data.p,
-                           (int32_t*)R->det_node.p);
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
-    lap("hits");
-    HIP_TRY(hipEventRecord(ev_t1, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
     float tms = 0;
     HIP_TRY(hipEventElapsedTime(&tms, ev_t0, ev_t1));
     R->total_ms = tms;

@@ -243,7 +243,7 @@ typedef struct bmo_trace_result_view {
     int64_t n_records;
     int64_t n_intersect_calls;  /* intersect3d(object|hint shape, ray) calls the reference
                                    algorithm performs for this trace (BASELINE metric) */
-    int32_t n_steps;            /* step-kernel launches (each advances every active beam by up to 16 bounces) */
+    int32_t n_steps;            /* step-kernel launches (each advances every active beam by up to 32 bounces) */
     int32_t beam_kind;
     int32_t rec_planes;         /* planes per record                                 */
     int32_t n_detectors;

@@ -44,7 +44,7 @@ def test_c1_bit_exact(engine_ok, oracle):
     got, ref = run_both(oracle, system, c1_bundle(1000))
     compare(got, ref, 0.0, "c1")
     deepest = int(ref.node_nseg.max())
-    assert (deepest + 15) // 16 <= got.n_steps <= deepest  # launches: up to 16 bounce levels are fused into one
+    assert (deepest + 31) // 32 <= got.n_steps <= deepest  # launches: up to 32 bounce levels are fused into one
 
 
 def test_c2_bit_exact(engine_ok, oracle):
