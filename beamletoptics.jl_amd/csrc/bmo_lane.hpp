@@ -389,10 +389,9 @@ BMO_HD Dual asph_leaf(CShape&, CDouble*, const Dual&, const Dual&) { return Dual
 // ASPH ("extended shapes"): compile the aspheric and cylinder-lens branches in.  Scenes without them run kernels
 // instantiated with ASPH = false (half the code, fewer registers).
 template <class T, bool ASPH>
-BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
-    // every table read of this leaf in one batch (the reads are LDS / scalar-cache round trips of ~100 cycles each: issued one by
-    // one at their points of use they, not the arithmetic, set the pace of the march)
-    const int kind = BMO_UNIFORM(s.kind);
+BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
+    // every table read of this leaf in one batch (the reads are LDS round trips of ~100 cycles each: issued one by one at their
+    // points of use they, not the arithmetic, set the pace of the march); `kind` comes from the caller, who has read it already
     const double P0 = s.p[0], P1 = s.p[1], P2 = s.p[2], P3 = s.p[3];
     v3<T> p = to_local(s, pt);
     if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
@@ -501,7 +500,8 @@ BMO_HD T sdf_leaf(CShape& s, const v3<T>& pt, CDouble* coefs) {
 // leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
 template <class T, bool ASPH>
 BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
-    const bool men = BMO_UNIFORM(s.kind) == BMO_SHAPE_MENISCUS;
+    const int kind0 = BMO_UNIFORM(s.kind);
+    const bool men = kind0 == BMO_SHAPE_MENISCUS;
     v3<T> p = pt;
     if (men) p = to_local(s, pt);
     const int nleaf = men ? 3 : 1;
@@ -509,7 +509,7 @@ BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
         CShape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
-        T v = sdf_leaf<T, ASPH>(leaf, p, S.coefs);
+        T v = sdf_leaf<T, ASPH>(leaf, men ? BMO_UNIFORM(leaf.kind) : kind0, p, S.coefs);
         if (q == 0) a = v;
         else if (q == 1) b = v;
         else c = v;
@@ -551,14 +551,29 @@ BMO_HD void child_cache_reset(ChildCache& cc) {
 // compare: `others_lb` is the smallest stored bound among the other children, so `others_lb - acc > bound` implies each child's own
 // test; the stored values are then left alone and only `acc`, the distance moved since they were stored, grows.  Otherwise every
 // child is looked at (evaluated, or its bound re-based to this point), which zeroes `acc` again.
+// The integer fields of a shape's table entry, read ONCE per intersect3d (every march iteration used to re-read them from LDS, one
+// dependent round trip each, because the compiler cannot hoist a load over the child-cache stores of the loop).
+struct ShapeHead {
+    int32_t kind, child_count, flags;  // wave-uniform (BMO_UNIFORM)
+    int32_t child_begin, tri_begin;    // per lane
+};
+BMO_HD ShapeHead shape_head(CShape& s) {
+    ShapeHead h;
+    h.kind = BMO_UNIFORM(s.kind);
+    h.child_count = BMO_UNIFORM(s.child_count);
+    h.flags = BMO_UNIFORM(s.flags);
+    h.child_begin = s.child_begin;
+    h.tri_begin = s.tri_begin;
+    return h;
+}
 template <bool ASPH>
-BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_child, ChildCache& cc, double moved) {
+BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d3& p, int32_t& best_child, ChildCache& cc, double moved) {
 #if defined(BMO_EMU_STATS)
     ++g_emu_sdf_any;
 #endif
     const v3<double> pt{p.x, p.y, p.z};
-    const bool uni = BMO_UNIFORM(s.kind) == BMO_SHAPE_UNION;
-    const int nch = uni ? BMO_UNIFORM(s.child_count) : 1;
+    const bool uni = H.kind == BMO_SHAPE_UNION;
+    const int nch = uni ? H.child_count : 1;
     double best = kinf();
     best_child = 0;
     bool have = false;
@@ -568,9 +583,9 @@ BMO_HD double sdf_any(const SceneView& S, CShape& s, const d3& p, int32_t& best_
     const double acc = cc.acc + (moved * (1.0 + 1e-9) + 1e-12);  // |dir| is 1 only to rounding
     // children stored back to back in the shape table (the usual case; flagged by the engine when it copies the scene): child c is
     // shape first_id + c, no look-up in children[]
-    const int32_t sflags = BMO_UNIFORM(s.flags);
+    const int32_t sflags = H.flags;
     const bool consecutive = uni && (sflags & BMO_SHAPE_FLAG_CONSECUTIVE);
-    const int32_t cb = s.child_begin, first_id = s.tri_begin;
+    const int32_t cb = H.child_begin, first_id = H.tri_begin;
     const bool all_exact = !(sflags & BMO_SHAPE_FLAG_INEXACT);
     double m1 = kinf(), m2 = kinf();  // the two smallest bounds stored by this evaluation, and whose the smallest is
     int i1 = -1;
@@ -668,9 +683,9 @@ BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
 }
 // normal3d of shape `sid` (table entry `s`) or, for a UnionSDF, of its arg-min child
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, int32_t sid, CShape& s, const d3& p, int32_t best_child) {
+BMO_HD d3 normal_any(const SceneView& S, int32_t sid, const ShapeHead& H, const d3& p, int32_t best_child) {
     int32_t tid = sid;
-    if (BMO_UNIFORM(s.kind) == BMO_SHAPE_UNION) tid = S.children[s.child_begin + best_child];
+    if (H.kind == BMO_SHAPE_UNION) tid = S.children[H.child_begin + best_child];
 #if defined(BMO_WATERFALL)
     // one pass per distinct class among the lanes' shapes (the arg-min children of a union may be of different kinds)
     d3 n{0, 0, 0};
@@ -751,10 +766,11 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         if (t_lb < 0.0) return h;                            // provable `nothing`
         if (t_lb * (1.0 - 1e-9) - 1e-9 > t_limit) return h;  // provable loser of the nearest-hit selection
     }
-    if (BMO_UNIFORM(s.kind) == BMO_SHAPE_MESH) {
+    const ShapeHead H = shape_head(s);
+    if (H.kind == BMO_SHAPE_MESH) {
         int fid = -1;
         double t0 = kinf();
-        const int ntri = BMO_UNIFORM(s.tri_count), tri0 = s.tri_begin;
+        const int ntri = BMO_UNIFORM(s.tri_count), tri0 = H.tri_begin;
         BMO_NOUNROLL
         for (int i = 0; i < ntri; ++i) {
             double t = moeller_trumbore(S.tris + 9 * (tri0 + i), pos0, dir0, S.mt_keps, S.mt_leps);
@@ -773,7 +789,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         return h;
     }
     enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2 };
-    const bool exact = !(BMO_UNIFORM(s.flags) & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
+    const bool exact = !(H.flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
     int phase = CLASSIFY;
     d3 pos = pos0, dir = dir0;
     double dist = 0.0, t0 = 0.0, t_in = 0.0;
@@ -798,7 +814,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
                 pos = axpy3(pos, dist, dir);
                 moved = fabs(dist);
             }
-            d = sdf_any<ASPH>(S, s, pos, bc, cc, moved);
+            d = sdf_any<ASPH>(S, H, s, pos, bc, cc, moved);
             bool give_up = false;  // the reference returns `nothing` here
             if (phase == CLASSIFY) {
                 if (d > S.eps_srf) {
@@ -841,7 +857,7 @@ BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, cons
         pending = false;
         // single normal evaluation site: the reference's normal3d, for the start classification on the surface
         // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the hit
-        const d3 n = normal_any<ASPH>(S, sid, s, pos, bc);
+        const d3 n = normal_any<ASPH>(S, sid, H, pos, bc);
         if (phase == CLASSIFY) {
             if (dot3(dir, n) <= 0) {  // entering
                 phase = INSIDE;
