@@ -786,6 +786,32 @@ __global__ void pack_keys_kernel(const int32_t* __restrict__ root_of, const unsi
     if (k32) k32[i] = (uint32_t)packed;
     else k64[i] = packed;
 }
+// ---- ordering of shallow trees (up to MAX_HEAP_LEVELS levels below the root: what one to five splitters in a row give) without a
+// sort: node (depth, path) sits at index 2^depth - 1 + path of its root's tree laid out as a heap, and heap order IS (depth, path)
+// order.  Every root collects the heap indices of its nodes in one 64-bit word; a node's position in the canonical order is then
+// (number of nodes of the roots before its own: one scan over the roots) + (number of set bits below its own).
+constexpr int MAX_HEAP_LEVELS = 5;
+__device__ __forceinline__ unsigned heap_index(unsigned long long key) {
+    const unsigned depth = (unsigned)(key >> 32);
+    return (1u << depth) - 1u + (unsigned)(key & ((1ull << depth) - 1ull));
+}
+__global__ void tree_bits_kernel(const int32_t* __restrict__ root_of, const unsigned long long* __restrict__ key, int64_t n, unsigned long long* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicOr(&bits[root_of[i]], 1ull << heap_index(key[i]));
+}
+__global__ void tree_count_kernel(const unsigned long long* __restrict__ bits, int64_t n_roots, int32_t* __restrict__ cnt) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_roots) cnt[r] = __popcll(bits[r]);
+}
+__global__ void tree_rank_kernel(const int32_t* __restrict__ root_of, const unsigned long long* __restrict__ key, int64_t n, const unsigned long long* __restrict__ bits,
+                                 const int32_t* __restrict__ base, int32_t* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = root_of[i];
+    const unsigned h = heap_index(key[i]);
+    order[base[r] + __popcll(bits[r] & ((1ull << h) - 1ull))] = (int32_t)i;
+}
 // ---- ordering of beam trees deeper than MAX_PATH_LEVELS (cavities: a splitter facing a mirror): the path no longer fits a key, so
 // the rank of every node within its tree level is built level by level from its parent's rank (a splitting beam has exactly two
 // children, transmitted first): rank(child) = 2 * #(splitting parents of smaller rank) + w.
@@ -1561,8 +1587,28 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // ---- canonical node order (bundle order x BFS order): sort by (root, depth, path)
     if ((rc = R->order.alloc((size_t)std::max<int64_t>(n_nodes, 1) * 4))) return rc;
     const unsigned nb = (unsigned)((n_nodes + 255) / 256);
-    if (n_nodes > 0) hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, stream, (int32_t*)R->order.p, n_nodes);
-    if (n_nodes > n) {
+    // test hooks: BMO_FORCE_SORT_ORDER / BMO_FORCE_DEEP_ORDER take the radix-sort / level-by-level path for any tree
+    const bool heap_order = n_nodes > n && h_ctr.max_depth <= (unsigned long long)MAX_HEAP_LEVELS && !std::getenv("BMO_FORCE_SORT_ORDER") &&
+                            !std::getenv("BMO_FORCE_DEEP_ORDER");
+    if (heap_order) {
+        DevBuf *bits = temp((size_t)n * 8), *cnt = temp((size_t)n * 4), *base = temp((size_t)n * 4);
+        if (!bits || !cnt || !base) return BMO_ERR_OOM;
+        const unsigned rb = (unsigned)((n + 255) / 256);
+        HIP_TRY(hipMemsetAsync(bits->p, 0, (size_t)n * 8, stream));
+        hipLaunchKernelGGL(tree_bits_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes,
+                           (unsigned long long*)bits->p);
+        hipLaunchKernelGGL(tree_count_kernel, dim3(rb), dim3(256), 0, stream, (const unsigned long long*)bits->p, n, (int32_t*)cnt->p);
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)cnt->p, (int32_t*)base->p, (int)n, stream));
+        DevBuf* st = temp(tmp_bytes);
+        if (!st) return BMO_ERR_OOM;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(st->p, tmp_bytes, (const int32_t*)cnt->p, (int32_t*)base->p, (int)n, stream));
+        hipLaunchKernelGGL(tree_rank_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes,
+                           (const unsigned long long*)bits->p, (const int32_t*)base->p, (int32_t*)R->order.p);
+    } else if (n_nodes > 0) {
+        hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, stream, (int32_t*)R->order.p, n_nodes);
+    }
+    if (n_nodes > n && !heap_order) {
         auto bits_for = [](unsigned long long v) {  // bits needed to hold values 0..v
             int b = 0;
             while (b < 64 && (v >> b)) ++b;
@@ -1570,7 +1616,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         };
         const int bits_depth = bits_for(h_ctr.max_depth), bits_root = bits_for((unsigned long long)std::max<int64_t>(n - 1, 0));
         DevBuf keys_in, keys_out, vals_out, tmp;
-        const bool force_deep = std::getenv("BMO_FORCE_DEEP_ORDER") != nullptr;  // test hook: take the deep-tree path for any tree
+        const bool force_deep = std::getenv("BMO_FORCE_DEEP_ORDER") != nullptr;
         if (h_ctr.max_depth <= (unsigned long long)MAX_PATH_LEVELS && !force_deep) {
             const int bits_path = (int)h_ctr.max_depth;  // one bit per level
             const int bits = bits_root + bits_depth + bits_path;

@@ -336,14 +336,14 @@ def test_engine_photodetector_field_on_random_scenes(oracle, seed):
 
 
 # ---------------------------------------------------------------------------------------------------------------- kernel variants
-VARIANTS = [{"BMO_NO_LDS": "1"}, {"BMO_FUSE": "1"}, {"BMO_FUSE": "3"}, {"BMO_FORCE_DEEP_ORDER": "1"}, {"BMO_NO_LDS": "1", "BMO_FUSE": "2"}]
+VARIANTS = [{"BMO_NO_LDS": "1"}, {"BMO_FUSE": "1"}, {"BMO_FUSE": "3"}, {"BMO_FORCE_DEEP_ORDER": "1"}, {"BMO_FORCE_SORT_ORDER": "1"}, {"BMO_NO_LDS": "1", "BMO_FUSE": "2"}]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_engine_variants_on_random_scenes(oracle, monkeypatch, env):
     """The engine's other code paths — scene tables read from global memory instead of LDS (what a scene > 120 KB gets), other
-    fused-level counts, the level-by-level node ordering of deep trees — on a slice of the random scenes, incl. a retrace."""
+    fused-level counts, the radix-sort and the level-by-level node ordering of trees deeper than 5 / 26 levels — on a slice of the random scenes, incl. a retrace."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for seed, kind in CASES[0:96:8] + [(DEEP, "ray")]:
