@@ -177,6 +177,9 @@ struct StepParams {
     int32_t r_max;
     int32_t parity;   // step & 1: which next_count slot this launch fills
     OldSolution old;  // RETR kernels only
+#if defined(BMO_DEV_TIMELINE)
+    unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
+#endif
 };
 
 // Per-lane retrace context (shared by the Beam and the GaussianBeamlet step kernels; tests/emu walks the same rules)
@@ -294,6 +297,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count;
     const bool valid = j < m;
+#if defined(BMO_DEV_TIMELINE)
+    if (P.tl && (threadIdx.x & 63) == 0) P.tl[2 * (j >> 6)] = wall_clock64();
+#endif
 
     // A lane carries nothing but `alive` from one fused bounce to the next: it writes its next record and reads it back at the
     // top of the next iteration (its own store, served by L1/L2) — keeping the ray in registers across the march instead costs
@@ -455,6 +461,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         //      across the march of the next iteration): mark the levels not reached, then compact into the next launch's chunk
         if (valid)
             for (int bb = b + 1; bb < P.n_fuse; ++bb) P.inner[bb - 1].i[I_NODE * P.inner[bb - 1].cap + j] = -1;
+#if defined(BMO_DEV_TIMELINE)
+        if (P.tl && (threadIdx.x & 63) == 0) P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
+#endif
         const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
         const int64_t ncap = P.nxt.cap;
         auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
@@ -1507,6 +1516,15 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.r_max = opts->r_max;
         P.parity = steps & 1;
         P.old = old_tab;
+#if defined(BMO_DEV_TIMELINE)  // developer builds, BMO_TIMELINE=1: how many waves are at work over the course of every launch
+        DevBuf tl_buf;
+        P.tl = nullptr;
+        if (getenv("BMO_TIMELINE")) {
+            if ((rc = tl_buf.alloc((size_t)((m + 63) / 64) * 16))) return rc;
+            HIP_TRY(hipMemsetAsync(tl_buf.p, 0, tl_buf.bytes, stream));
+            P.tl = (unsigned long long*)tl_buf.p;
+        }
+#endif
         DBG("step %d launching m=%lld", steps, (long long)m);
         // launch timing: one event pair per step out of a cached pool, read after the loop (nothing but the counter read-back
         // sits between two launches)
@@ -1521,6 +1539,28 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
+#if defined(BMO_DEV_TIMELINE)
+        if (P.tl) {
+            const size_t nw = (size_t)((m + 63) / 64);
+            std::vector<unsigned long long> t(2 * nw);
+            HIP_TRY(hipMemcpy(t.data(), P.tl, nw * 16, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t w = 0; w < nw; ++w) {
+                t0 = std::min(t0, t[2 * w]);
+                t1 = std::max(t1, t[2 * w + 1]);
+            }
+            const double span = (double)(t1 - t0);
+            const int NB = 40;
+            std::vector<double> busy(NB, 0.0);  // wave residency integrated per bin
+            for (size_t w = 0; w < nw; ++w) {
+                const double a = (double)(t[2 * w] - t0) / span * NB, b2 = (double)(t[2 * w + 1] - t0) / span * NB;
+                for (int q = (int)a; q < NB && q <= (int)b2; ++q) busy[q] += std::min(b2, (double)q + 1) - std::max(a, (double)q);
+            }
+            fprintf(stderr, "[bmo] timeline step %d: %zu waves, span %.3f ms; mean waves at work per 1/%d of the span:\n ", steps, nw, span / 1e5, NB);
+            for (int q = 0; q < NB; ++q) fprintf(stderr, " %.0f", busy[q]);
+            fprintf(stderr, "\n");
+        }
+#endif
         const unsigned long long produced = h_ctr.next_count[steps & 1];
         DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
         steps += 1;
