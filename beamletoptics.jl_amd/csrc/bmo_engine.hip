@@ -123,7 +123,16 @@ struct Chunk {
     int32_t* i;  // [NI][cap]
     int64_t cap;
     int64_t count;
+    // In-place level `level` (1..) of a fused launch: the slots of wave w (64 consecutive slots) hold records or hole marks only if that
+    // wave got as far as this level, wl[w] >= level; what lies beyond was never written.  wl == nullptr: every slot below count is a record.
+    const uint8_t* wl = nullptr;
+    int32_t level = 0;
 };
+// node id of record j of a chunk of the log, -1 where there is none (a beam that ended earlier, or a level its wave did not reach)
+__device__ __forceinline__ int32_t chunk_node(const Chunk& c, int64_t j) {
+    if (c.wl && c.level > (int32_t)c.wl[j >> 6]) return -1;
+    return c.i[I_NODE * c.cap + j];
+}
 
 struct Counters {  // device-resident, one per trace
     // records written to the next chunk.  Two slots: step s accumulates into slot s & 1 and clears the other one for step s + 1
@@ -132,6 +141,7 @@ struct Counters {  // device-resident, one per trace
     unsigned long long node_count;
     unsigned long long max_depth;  // deepest beam-tree level created so far (sizes the sort keys of the final ordering)
     unsigned long long overflow;
+    unsigned long long max_level[2];  // deepest in-place level any wave of the launch reached (slots used like next_count's)
 };
 
 struct NodeArrays {
@@ -177,6 +187,7 @@ struct StepParams {
     int32_t r_max;
     int32_t parity;   // step & 1: which next_count slot this launch fills
     OldSolution old;  // RETR kernels only
+    uint8_t* wave_last;  // [waves of the launch]: the last in-place level each wave reached (nullptr: nobody will read the log)
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
 #endif
@@ -217,8 +228,8 @@ struct SlotAlloc {
     unsigned long long surv_base, child_base, node_base;
     unsigned long long m_surv, m_split;
 };
-__device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint32_t calls, const StepParams& P, char* scratch) {
-    uint32_t* w32 = reinterpret_cast<uint32_t*>(scratch);                         // [0..3] surv, [4..7] split
+__device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint32_t calls, const StepParams& P, char* scratch, int level = 0) {
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(scratch);                         // [0..3] surv, [4..7] split, [8..11] calls, [12..15] level
     unsigned long long* w64 = reinterpret_cast<unsigned long long*>(scratch + 32);  // [0] base, [1] nbase
     SlotAlloc a;
     a.m_surv = __ballot(survive);
@@ -230,15 +241,18 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
         w32[wave] = (uint32_t)__popcll(a.m_surv);
         w32[4 + wave] = (uint32_t)__popcll(a.m_split);
         w32[8 + wave] = c;
+        w32[12 + wave] = (uint32_t)level;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t ts = 0, tp = 0, tc = 0;
+        uint32_t ts = 0, tp = 0, tc = 0, ml = 0;
         for (int w = 0; w < BMO_BLOCK / 64; ++w) {
             ts += w32[w];
             tp += w32[4 + w];
             tc += w32[8 + w];
+            ml = w32[12 + w] > ml ? w32[12 + w] : ml;
         }
+        if (ml) atomicMax(&P.ctr->max_level[P.parity], (unsigned long long)ml);
         unsigned long long b = 0, nb = 0;
         if (ts + tp) b = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(ts + 2 * tp));
         if (tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
@@ -292,7 +306,10 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     extern __shared__ __attribute__((aligned(16))) char lds[];
     SceneView S = stage_scene<LDS>(P, lds);
     char* scratch = lds + (LDS ? P.blob_bytes : 0u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.ctr->next_count[P.parity ^ 1] = 0;
+        P.ctr->max_level[P.parity ^ 1] = 0;
+    }
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count;
@@ -457,14 +474,14 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             b += 1;
             continue;
         }
-        // ---- last fused bounce of this workgroup (kept inside the loop so that o.next / o.refl die here instead of staying live
-        //      across the march of the next iteration): mark the levels not reached, then compact into the next launch's chunk
-        if (valid)
-            for (int bb = b + 1; bb < P.n_fuse; ++bb) P.inner[bb - 1].i[I_NODE * P.inner[bb - 1].cap + j] = -1;
+        // ---- last fused bounce of this wave (kept inside the loop so that o.next / o.refl die here instead of staying live
+        //      across the march of the next iteration): note how far the wave got — the in-place levels beyond are never written and
+        //      never read (Chunk::wl) —, then compact into the next launch's chunk
+        if (P.wave_last && lane_id() == 0) P.wave_last[j >> 6] = (uint8_t)b;
 #if defined(BMO_DEV_TIMELINE)
         if (P.tl && (threadIdx.x & 63) == 0) P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
 #endif
-        const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
+        const SlotAlloc al = block_alloc(survive, split, calls, P, scratch, b);
         const int64_t ncap = P.nxt.cap;
         auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
             if (slot >= ncap) {
@@ -772,8 +789,9 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
 __global__ void old_obj_scatter_kernel(Chunk c, const int32_t* __restrict__ rec_start, int32_t* __restrict__ rec_obj) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
-    const int32_t node = c.i[I_NODE * c.cap + j], k = c.i[I_K * c.cap + j];
+    const int32_t node = chunk_node(c, j);
     if (node < 0) return;  // hole of a fused level
+    const int32_t k = c.i[I_K * c.cap + j];
     rec_obj[(int64_t)rec_start[node] + k] = c.i[I_OBJ * c.cap + j];
 }
 __global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key, int64_t n, int32_t* __restrict__ first_child) {
@@ -959,7 +977,7 @@ __global__ void last_records_kernel(Chunk c, int planes, const int32_t* __restri
                                     int32_t* __restrict__ obj, int32_t* __restrict__ shape) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
-    const int32_t nd = c.i[I_NODE * c.cap + j];
+    const int32_t nd = chunk_node(c, j);
     if (nd < 0) return;  // hole of a fused level
     if (c.i[I_K * c.cap + j] != nseg[nd] - 1) return;
     const int64_t dst = rank[nd];
@@ -981,7 +999,7 @@ __global__ void order_records_kernel(Chunk c, int planes, const int32_t* __restr
                                      int32_t* __restrict__ obj, int32_t* __restrict__ shape) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
-    const int32_t nd = c.i[I_NODE * c.cap + j];
+    const int32_t nd = chunk_node(c, j);
     if (nd < 0) return;  // hole of a fused level
     const int64_t dst = (int64_t)dst_base[nd] + c.i[I_K * c.cap + j];
     for (int p = 0; p < planes; ++p) rec[(int64_t)p * nr + dst] = c.d[(int64_t)p * c.cap + j];
@@ -1174,6 +1192,7 @@ struct bmo_trace_result {
     int64_t view_records = 0;
     bool has_log = true;                         // false: solved with record_segments = 0, only beams and detector hits were kept
     std::vector<Chunk> chunks;
+    std::vector<std::unique_ptr<DevBuf>> wave_last;  // Chunk::wl of the fused launches
     DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, n_aux, order, det_data, det_node;
     DevBuf n_old;  // retrace runs only (NodeArrays::old)
     // tables a later bmo_retrace of THIS solution needs, built on first use (OldSolution)
@@ -1414,7 +1433,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     Counters* d_ctr = static_cast<Counters*>(ctr_buf.p);
     Counters* h_ctr_p = ctx.pinned;  // pinned: the per-step read-back does not go through a staging copy
     Counters& h_ctr = *h_ctr_p;
-    h_ctr = Counters{{0, 0}, (unsigned long long)n, 0, 0};
+    h_ctr = Counters{{0, 0}, (unsigned long long)n, 0, 0, {0, 0}};
     HIP_TRY(hipMemcpyAsync(d_ctr, h_ctr_p, sizeof h_ctr, hipMemcpyHostToDevice, stream));
 
     Chunk cur;
@@ -1492,6 +1511,18 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         // the in-place levels of a launch are allocated up front: at most 24 GB of them (2^24 beams: 8 levels)
         if (keep_log) n_fuse = (int)std::min<int64_t>(n_fuse, 1 + (int64_t)(((size_t)24 << 30) / ((size_t)std::max<int64_t>(m, 1) * rec_bytes)));
         Chunk nxt, inner[MAX_FUSE - 1];
+        // the next launch's chunk first, then the in-place levels: the levels no wave reaches go back to the arena after the launch
+        if ((rc = new_chunk(has_split ? 2 * m : m, nxt))) return rc;
+        uint8_t* wl = nullptr;
+        if (keep_log && n_fuse > 1) {
+            auto b = std::make_unique<DevBuf>();
+            if ((rc = b->alloc((size_t)((m + 63) / 64)))) return rc;
+            wl = static_cast<uint8_t*>(b->p);
+            R->wave_last.push_back(std::move(b));
+        }
+        size_t top_after[MAX_FUSE], blocks_after[MAX_FUSE];  // arena state behind nxt [0] and behind every in-place level [q + 1]
+        top_after[0] = top;
+        blocks_after[0] = R->arena.size();
         for (int q = 0; q + 1 < n_fuse; ++q) {
             if (!keep_log && q > 0) {
                 inner[q] = inner[0];  // nobody reads the log: a lane's in-place record is dead once it has been read back, one chunk serves all levels
@@ -1499,8 +1530,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             }
             if ((rc = new_chunk(m, inner[q]))) return rc;
             inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
+            inner[q].wl = wl;
+            inner[q].level = q + 1;
+            top_after[q + 1] = top;
+            blocks_after[q + 1] = R->arena.size();
         }
-        if ((rc = new_chunk(has_split ? 2 * m : m, nxt))) return rc;
         if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
         StepParams P;
         P.blob = dblob;
@@ -1516,6 +1550,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.r_max = opts->r_max;
         P.parity = steps & 1;
         P.old = old_tab;
+        P.wave_last = wl;
 #if defined(BMO_DEV_TIMELINE)  // developer builds, BMO_TIMELINE=1: how many waves are at work over the course of every launch
         DevBuf tl_buf;
         P.tl = nullptr;
@@ -1566,8 +1601,15 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
         if (keep_log) {
+            const int used = (int)std::min<unsigned long long>(h_ctr.max_level[(steps - 1) & 1], (unsigned long long)(n_fuse - 1));  // in-place levels reached
             R->chunks.push_back(cur);
-            for (int q = 0; q + 1 < n_fuse; ++q) R->chunks.push_back(inner[q]);
+            for (int q = 0; q < used; ++q) R->chunks.push_back(inner[q]);
+            // the levels behind them were never touched: their room goes back to the arena (allocation is a bump, so everything
+            // allocated after the last level in use belongs to them)
+            if (used + 1 < n_fuse) {
+                while (R->arena.size() > blocks_after[used]) R->arena.pop_back();
+                top = top_after[used];
+            }
         } else {  // the launch above has completed (counter read-back): its input and in-place levels are dead
             drop_chunk(cur);
             if (n_fuse > 1) drop_chunk(inner[0]);

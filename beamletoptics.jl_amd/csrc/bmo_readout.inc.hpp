@@ -163,7 +163,7 @@ __global__ void pd_gather_kernel(Chunk c, const int32_t* __restrict__ node_hit, 
                                  double* __restrict__ segs, double* __restrict__ hs) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
-    const int32_t nd = c.i[I_NODE * c.cap + j];
+    const int32_t nd = chunk_node(c, j);
     if (nd < 0) return;  // hole of a fused level
     const int32_t h = node_hit[nd];
     if (h < 0) return;
