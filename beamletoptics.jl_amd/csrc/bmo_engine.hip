@@ -1507,7 +1507,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
     while (cur.count > 0) {
         const int64_t m = cur.count;
-        int n_fuse = keep_ratio >= 0.9 ? fuse_max : (keep_ratio >= 0.6 ? std::min(2, fuse_max) : 1);
+        static const double keep_hi = getenv("BMO_KEEP_HI") ? atof(getenv("BMO_KEEP_HI")) : 0.9, keep_lo = getenv("BMO_KEEP_LO") ? atof(getenv("BMO_KEEP_LO")) : 0.6;
+        static const int fuse_mid = getenv("BMO_FUSE_MID") ? atoi(getenv("BMO_FUSE_MID")) : 2, fuse_lo = getenv("BMO_FUSE_LO") ? atoi(getenv("BMO_FUSE_LO")) : 1;
+        int n_fuse = keep_ratio >= keep_hi ? fuse_max : (keep_ratio >= keep_lo ? std::min(fuse_mid, fuse_max) : std::min(fuse_lo, fuse_max));
         // the in-place levels of a launch are allocated up front: at most 24 GB of them (2^24 beams: 8 levels)
         if (keep_log) n_fuse = (int)std::min<int64_t>(n_fuse, 1 + (int64_t)(((size_t)24 << 30) / ((size_t)std::max<int64_t>(m, 1) * rec_bytes)));
         Chunk nxt, inner[MAX_FUSE - 1];
