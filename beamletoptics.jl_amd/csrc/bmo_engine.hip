@@ -69,7 +69,8 @@ struct BlobHeader {
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
-    uint32_t has_asphere, pad;
+    uint32_t has_asphere, off_objbs;
+    uint32_t off_objnp, pad;
 };
 
 template <class CharPtr>
@@ -82,6 +83,8 @@ __host__ __device__ inline SceneView view_of(CharPtr blob) {
     S.tris = (CDouble*)(blob + h->off_tris);
     S.n_table = (CDouble*)(blob + h->off_ntable);
     S.coefs = (CDouble*)(blob + h->off_coefs);
+    S.obj_bs = (CDouble*)(blob + h->off_objbs);
+    S.obj_np = (CInt*)(blob + h->off_objnp);
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -349,6 +352,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     };
 
     int b = 0;  // fused bounce index: records of bounce b live in C = (b == 0 ? P.cur : P.inner[b - 1]) at slot j
+#if defined(BMO_DEV_TIMELINE)
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk_last = wall_clock64();  // time before / in / after tracing_step, summed over the levels
+#endif
     for (;;) {
         const Chunk C = b == 0 ? P.cur : P.inner[b - 1];
         bool survive = false, split = false, still = false, old_kids = false;
@@ -403,7 +409,21 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             } else {
                 // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
                 ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+#if defined(BMO_DEV_TIMELINE)
+                {
+                    const unsigned long long t = wall_clock64();
+                    tk0 += t - tk_last;
+                    tk_last = t;
+                }
+#endif
                 X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, ho, hs, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+#if defined(BMO_DEV_TIMELINE)
+                {
+                    const unsigned long long t = wall_clock64();
+                    tk1 += t - tk_last;
+                    tk_last = t;
+                }
+#endif
                 if (X.shape < 0) {
                     status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 } else {
@@ -454,6 +474,13 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 }
             }
         }
+#if defined(BMO_DEV_TIMELINE)
+        {
+            const unsigned long long t = wall_clock64();
+            tk2 += t - tk_last;
+            tk_last = t;
+        }
+#endif
         bool go_on = b + 1 < P.n_fuse;
         // wave-uniform decisions: every wave runs its own fused loop (no workgroup barrier per level: the four waves of a workgroup used to
         // wait for the slowest of them at every bounce); the workgroup meets again at block_alloc below
@@ -480,7 +507,13 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         //      never read (Chunk::wl) —, then compact into the next launch's chunk
         if (P.wave_last && lane_id() == 0) P.wave_last[j >> 6] = (uint8_t)b;
 #if defined(BMO_DEV_TIMELINE)
-        if (P.tl && (threadIdx.x & 63) == 0) P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
+        if (P.tl && (threadIdx.x & 63) == 0) {
+            P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
+            const int64_t nw = (P.cur.count + 63) / 64;
+            atomicAdd(&P.tl[2 * nw + 0], tk0);
+            atomicAdd(&P.tl[2 * nw + 1], tk1);
+            atomicAdd(&P.tl[2 * nw + 2], tk2);
+        }
 #endif
         const SlotAlloc al = block_alloc(survive, split, calls, P, scratch, b);
         const int64_t ncap = P.nxt.cap;
@@ -1558,7 +1591,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         DevBuf tl_buf;
         P.tl = nullptr;
         if (getenv("BMO_TIMELINE")) {
-            if ((rc = tl_buf.alloc((size_t)((m + 63) / 64) * 16))) return rc;
+            if ((rc = tl_buf.alloc((size_t)((m + 63) / 64) * 16 + 64))) return rc;
             HIP_TRY(hipMemsetAsync(tl_buf.p, 0, tl_buf.bytes, stream));
             P.tl = (unsigned long long*)tl_buf.p;
         }
@@ -1580,8 +1613,14 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
 #if defined(BMO_DEV_TIMELINE)
         if (P.tl) {
             const size_t nw = (size_t)((m + 63) / 64);
-            std::vector<unsigned long long> t(2 * nw);
-            HIP_TRY(hipMemcpy(t.data(), P.tl, nw * 16, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> t(2 * nw + 3);
+            HIP_TRY(hipMemcpy(t.data(), P.tl, nw * 16 + 24, hipMemcpyDeviceToHost));
+            {
+                const double a = (double)t[2 * nw], b2 = (double)t[2 * nw + 1], c2 = (double)t[2 * nw + 2], sum = a + b2 + c2;
+                // (finer timers inside the lane code — per sdf_any / normal_any / object — measure mostly their own s_memrealtime latency)
+                fprintf(stderr, "[bmo] timeline step %d: wave time before / in / after tracing_step: %.1f %% / %.1f %% / %.1f %%  (%.1f us per wave in all)\n", steps,
+                        100 * a / sum, 100 * b2 / sum, 100 * c2 / sum, sum / nw / 100.0);
+            }
             unsigned long long t0 = ~0ull, t1 = 0;
             for (size_t w = 0; w < nw; ++w) {
                 t0 = std::min(t0, t[2 * w]);
@@ -1982,6 +2021,10 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     off = al(off + 8 * (size_t)std::max(1, d->n_media) * (size_t)d->n_lambda);
     h.off_coefs = (uint32_t)off;
     off = al(off + 8 * (size_t)std::max(1, d->n_coefs));
+    h.off_objbs = (uint32_t)off;
+    off = al(off + 96 * (size_t)std::max(1, d->n_objects));
+    h.off_objnp = (uint32_t)off;
+    off = al(off + 4 * (size_t)std::max(1, d->n_objects));
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -2022,6 +2065,19 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
+    for (int i = 0; i < d->n_objects; ++i) {  // the parts' bounding spheres and count, as tracing_step looks at them first (bmo_lane.hpp)
+        const bmo_object& o = d->objects[i];
+        const int np = (o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_PLATE_BS) ? 2 : (o.kind == BMO_OBJ_CUBE_BS ? 3 : (o.kind == BMO_OBJ_NONINTERACTABLE ? 0 : 1));
+        reinterpret_cast<int32_t*>(sc->blob.data() + h.off_objnp)[i] = np;
+        double* bs = reinterpret_cast<double*>(sc->blob.data() + h.off_objbs) + 12 * (size_t)i;
+        for (int k = 0; k < np; ++k) {
+            const bmo_shape& sh = d->shapes[o.shape[k]];
+            bs[4 * k + 0] = sh.bs_center[0];
+            bs[4 * k + 1] = sh.bs_center[1];
+            bs[4 * k + 2] = sh.bs_center[2];
+            bs[4 * k + 3] = sh.bs_radius;
+        }
+    }
     sc->hdr = h;
     *out = sc.release();
     return BMO_OK;
