@@ -121,7 +121,8 @@ BMO_HD double jmin_rule(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_HW_MINMAX)
 // Optional device form (-DBMO_HW_MINMAX): v_max_f64 / v_min_f64 order the zeros the same way (+0 > -0) and return the other operand for
 // a NaN, so one NaN select on top gives the rule without control flow (the rule form compiles to execution-mask branches).  Measured:
-// -1.5 % on config 5, -2 % on the vignetted bundle, +1 % on config 2 (profiles/r02_ab_minmax_forms.txt) — not the default;
+// -1.5 % on config 5, -2 % on the vignetted bundle, +1 % on config 2 at first (profiles/r02_ab_minmax_forms.txt), +4 % on config 2 and
+// +1 % on config 5 on the round's final code (profiles/r02_ab_uniform_ctrl.txt) — not the default;
 // bmo_selftest compares whichever form is compiled in with the rule, bit for bit on the special values, on the device.
 BMO_HD double jmax(double x, double y) {
     const double m = __builtin_fmax(x, y);
