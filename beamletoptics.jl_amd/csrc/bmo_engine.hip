@@ -69,8 +69,7 @@ struct BlobHeader {
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
-    uint32_t has_asphere, off_objbs;
-    uint32_t off_objnp, pad;
+    uint32_t has_asphere, pad;
 };
 
 template <class CharPtr>
@@ -83,8 +82,6 @@ __host__ __device__ inline SceneView view_of(CharPtr blob) {
     S.tris = (CDouble*)(blob + h->off_tris);
     S.n_table = (CDouble*)(blob + h->off_ntable);
     S.coefs = (CDouble*)(blob + h->off_coefs);
-    S.obj_bs = (CDouble*)(blob + h->off_objbs);
-    S.obj_np = (CInt*)(blob + h->off_objnp);
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -2021,10 +2018,6 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     off = al(off + 8 * (size_t)std::max(1, d->n_media) * (size_t)d->n_lambda);
     h.off_coefs = (uint32_t)off;
     off = al(off + 8 * (size_t)std::max(1, d->n_coefs));
-    h.off_objbs = (uint32_t)off;
-    off = al(off + 96 * (size_t)std::max(1, d->n_objects));
-    h.off_objnp = (uint32_t)off;
-    off = al(off + 4 * (size_t)std::max(1, d->n_objects));
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -2065,19 +2058,6 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
-    for (int i = 0; i < d->n_objects; ++i) {  // the parts' bounding spheres and count, as tracing_step looks at them first (bmo_lane.hpp)
-        const bmo_object& o = d->objects[i];
-        const int np = (o.kind == BMO_OBJ_DOUBLET || o.kind == BMO_OBJ_PLATE_BS) ? 2 : (o.kind == BMO_OBJ_CUBE_BS ? 3 : (o.kind == BMO_OBJ_NONINTERACTABLE ? 0 : 1));
-        reinterpret_cast<int32_t*>(sc->blob.data() + h.off_objnp)[i] = np;
-        double* bs = reinterpret_cast<double*>(sc->blob.data() + h.off_objbs) + 12 * (size_t)i;
-        for (int k = 0; k < np; ++k) {
-            const bmo_shape& sh = d->shapes[o.shape[k]];
-            bs[4 * k + 0] = sh.bs_center[0];
-            bs[4 * k + 1] = sh.bs_center[1];
-            bs[4 * k + 2] = sh.bs_center[2];
-            bs[4 * k + 3] = sh.bs_radius;
-        }
-    }
     sc->hdr = h;
     *out = sc.release();
     return BMO_OK;

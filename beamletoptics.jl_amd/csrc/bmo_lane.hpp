@@ -78,10 +78,6 @@ struct SceneView {
     CDouble* tris;
     CDouble* n_table;
     CDouble* coefs;
-    // engine-built (device image only, nullptr elsewhere): bounding spheres of every object's parts, 4 doubles {cx, cy, cz, R} for each of
-    // 3 part slots per object, and the number of parts of every object — what tracing_step's first look at an object needs, in one place
-    CDouble* obj_bs = nullptr;
-    CInt* obj_np = nullptr;
     int32_t n_objects, n_lambda;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int32_t march_iters;
@@ -928,24 +924,6 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_
         BMO_NOUNROLL
         for (int o = -1; o < o_hi; ++o) {  // the induction variable stays wave-uniform; lanes skip the slots they do not use
             if (o < 0 ? hs < 0 : (o < o_lo || o == skip_obj)) continue;
-#if defined(__HIP_DEVICE_COMPILE__)
-            // First look at an object: the two tests intersect_shape starts with (provable miss / provable loser of the nearest-hit
-            // selection), for all of its parts, from the compact sphere table.  When no lane of the wave passes them for any part, every
-            // intersect_shape below would return `nothing` at once: the wave goes to the next object without touching this one's
-            // records.  (Most of trace_all's objects end here: in config C2, 65 % of the bounces sweep all 10 objects for 1-2 candidates.)
-            if (o >= 0 && S.obj_bs) {
-                const int ou = BMO_UNIFORM(o);
-                const int npc = BMO_UNIFORM(S.obj_np[ou]);
-                const double lim0 = X.shape >= 0 ? X.t + 1e-6 * (1.0 + X.t) : kinf();
-                bool cand = false;
-                for (int k = 0; k < npc; ++k) {
-                    CDouble* b = S.obj_bs + 4 * (3 * ou + k);
-                    const double t_lb = cull_entry_raw(b[0], b[1], b[2], b[3], pos, dir);
-                    cand = cand || !(t_lb < 0.0 || t_lb * (1.0 - 1e-9) - 1e-9 > lim0);
-                }
-                if (!__any(cand ? 1 : 0)) continue;
-            }
-#endif
             int kind = BMO_OBJ_INTERSECTABLE, np = 1;
             int32_t sh0 = hs, sh1 = -1, sh2 = -1;
             if (o >= 0) {
