@@ -259,7 +259,10 @@ def main():
     dist = torch = None
     backend = None
     device_ord = 0
-    if world > 1:
+    # BMO_BENCH_FORCE_DIST=1 (under torchrun with one rank): take the N > 1 code path — process group, exchange step, collectives — with a
+    # world of one, e.g. to rehearse the RCCL calls on a one-GPU box (tests/test_multi_gpu.py)
+    multi = world > 1 or bool(os.environ.get("BMO_BENCH_FORCE_DIST"))
+    if multi:
         import torch
         import torch.distributed as dist
 
@@ -274,10 +277,10 @@ def main():
 
     import bmo_amd as bmo
 
-    if world > 1:
+    if multi:
         from bmo_amd import distributed as bd
 
-    name = args.workload or ("c2" if world == 1 else "c5")
+    name = args.workload or ("c5" if multi else "c2")
     n_local = args.rays or DEFAULT_RAYS[name]
     # Weak scaling: the global bundle is the concatenation, in rank order, of one complete bundle per GPU (same disc and cone
     # distribution, directions drawn from seed + rank), so every rank traces the same amount of work and its contiguous shard keeps
@@ -309,7 +312,7 @@ def main():
         return res, kms, nl
 
     def sync():
-        if world > 1:
+        if multi:
             finish_exchange()
             dist.barrier()
             torch.cuda.synchronize()
@@ -317,12 +320,12 @@ def main():
     # N > 1: this rank's rate WITHOUT the exchange step, same workload, measured before the timed region — the one-GPU reference
     # point of the same config, so that scaling can be read against the same work (N = 1 of the driver's curve runs config 2).
     local_only = None
-    if world > 1:
+    if multi:
         dt0, _, _, c0 = case.measure(args.r_max, max(2, min(args.steps, 3)), 1)
         local_only = c0["calls"] * max(2, min(args.steps, 3)) / dt0
 
     for _ in range(args.warmup):
-        res, _, _ = one_step(world > 1)
+        res, _, _ = one_step(multi)
         eng.free_result(res)
     sync()
     t0 = time.perf_counter()
@@ -330,12 +333,12 @@ def main():
     for _ in range(args.steps):
         if last is not None:
             eng.free_result(last)
-        last, kms, nl = one_step(world > 1)
+        last, kms, nl = one_step(multi)
         kernel_ms += kms
         launches += nl
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -345,7 +348,7 @@ def main():
     det_counts = eng.result_counts(last)
     eng.free_result(last)
     mine = dict(calls=calls, segments=nrec, nodes=nnodes, hits=hits, det_counts=det_counts)
-    if world > 1:
+    if multi:
         agg = torch.tensor([calls, nrec, hits, n_local, nnodes], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(agg)
         calls_all, traced_all, hits_all, rays_all, nodes_all = (float(x) for x in agg.cpu())
@@ -381,19 +384,19 @@ def main():
                 "name": name, "rays_per_gpu": n_local, "elements": case.scene.n_objects, "shapes": len(case.scene.shape_list),
                 "segments_per_step": int(traced_all), "beam_nodes": int(nodes_all), "detector_hits": int(hits_all),
                 "intersect3d_calls_per_step": int(calls_all),
-                "parallelism": f"ray-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all-gather of detector hits" if world > 1 else ""),
+                "parallelism": f"ray-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all-gather of detector hits" if multi else ""),
             },
             "roofline": roofline_of(case, mine, kernel_ms, launches, args.steps, traffic, traffic_src),
         }
         if local_only is not None:
             out["one_gpu_same_workload"] = {"value": local_only, "unit": "intersections/s",
                                             "what": "rank 0, same shard, solves only (no exchange step), measured before the timed region"}
-        if world == 1 and not args.no_extras:
+        if not multi and not args.no_extras:
             out["pcie"] = pcie_rates(case, args.r_max, calls)
-        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is reported at N = 1 only
+        if args.cpu_sample > 0 and not multi:  # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(case, min(args.cpu_sample, n_local), args.r_max)
     case.close()
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and not multi and not args.no_extras:
         # the other BASELINE configs at their per-GPU sizes, and the vignetted C2 bundle: 3 resident solves each after 1 warm-up
         cfgs = {}
         for other in ("c2v", "c3", "c4", "c5"):
@@ -410,7 +413,7 @@ def main():
         out["configs"] = cfgs
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

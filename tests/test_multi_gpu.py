@@ -219,3 +219,22 @@ def test_engine_sharded_hits_equal_unsharded(tmp_path):
     world = 2
     mp.spawn(_engine_worker, args=(world, _free_port(), 3072, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path — process group on the `nccl` backend (= RCCL), the exchange step with `all_gather_into_tensor` on
+    device tensors left in flight across solves, the barrier / max-over-ranks timing, the aggregate all-reduce — run for real with a
+    world of ONE rank under torchrun (two ranks cannot share the one GPU of the test box under RCCL; the two-rank logic is covered with
+    gloo above).  Catches API misuse of the collectives on device tensors before the driver's multi-GPU run does."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, BMO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rays", "65536", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-gather" in line["config"]["parallelism"]
+    assert line["config"]["name"] == "c5" and line["one_gpu_same_workload"]["value"] > 0
