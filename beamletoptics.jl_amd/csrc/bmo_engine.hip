@@ -776,7 +776,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
 
 // ------------------------------------------------------------------ small helper kernels
 template <int KIND>
-__global__ void init_roots_kernel(const double* planes, const int32_t* lambda_idx, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max) {
+__global__ void init_roots_kernel(const double* planes, const int32_t* lambda_idx, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max, int32_t n_planes) {
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -787,9 +787,15 @@ __global__ void init_roots_kernel(const double* planes, const int32_t* lambda_id
             for (int p = 0; p < 6; ++p) c0.d[(11 * b + p) * cap + j] = planes[(6 * b + p) * n + j];
             c0.d[(11 * b + 6) * cap + j] = planes[19 * n + j];
         }
-        for (int p = 33; p < 38; ++p) c0.d[p * cap + j] = 0.0;
+        // accumulated lengths: zero for a fresh beamlet; a batch that continues solved beamlets brings them along (include/bmo.h)
+        const bool cont = n_planes >= BMO_PLANES_GAUSSIAN_CONTINUED;
+        c0.d[33 * cap + j] = cont ? planes[25 * n + j] : 0.0;  // lenA
+        c0.d[34 * cap + j] = cont ? planes[26 * n + j] : 0.0;  // lenB
+        c0.d[35 * cap + j] = cont ? planes[28 * n + j] : 0.0;  // oplC
+        c0.d[36 * cap + j] = cont ? planes[29 * n + j] : 0.0;  // oplW
+        c0.d[37 * cap + j] = cont ? planes[30 * n + j] : 0.0;  // oplD
         lam = planes[18 * n + j];
-        nodes.aux[j * 4 + 0] = 0.0;
+        nodes.aux[j * 4 + 0] = cont ? planes[27 * n + j] : 0.0;  // l0
         nodes.aux[j * 4 + 1] = planes[20 * n + j];
         nodes.aux[j * 4 + 2] = planes[21 * n + j];
         nodes.aux[j * 4 + 3] = planes[22 * n + j];
@@ -1483,7 +1489,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (n > 0) {
         // a retrace re-walks the stored first ray whatever r_max says (System.jl:197); root j re-walks old node j
         hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
-                           (const int32_t*)batch->li.p, n, cur, node_arrays(), prev ? 0x7fffffff : opts->r_max);
+                           (const int32_t*)batch->li.p, n, cur, node_arrays(), prev ? 0x7fffffff : opts->r_max, (int32_t)batch->n_planes);
         if (prev) hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int32_t*)R->n_old.p, n);
     }
     lap("setup");
@@ -2077,7 +2083,8 @@ int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, 
     if (!scene || !in || !out) return fail(BMO_ERR_INVALID, "null argument");
     if (in->kind != BMO_BEAM_RAY && in->kind != BMO_BEAM_POLARIZED && in->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bad beam kind");
     const int want = in->kind == BMO_BEAM_RAY ? BMO_PLANES_RAY : (in->kind == BMO_BEAM_POLARIZED ? BMO_PLANES_POLARIZED : BMO_PLANES_GAUSSIAN);
-    if (in->n_planes != want || in->n < 0) return fail(BMO_ERR_INVALID, "bad plane count");
+    const bool continued = in->kind == BMO_BEAM_GAUSSIAN && in->n_planes == BMO_PLANES_GAUSSIAN_CONTINUED;
+    if ((in->n_planes != want && !continued) || in->n < 0) return fail(BMO_ERR_INVALID, "bad plane count");
     if (in->n > 0x7fffffff / 4) return fail(BMO_ERR_INVALID, "batch too large for one device (shard it)");
     for (int64_t i = 0; i < in->n; ++i)
         if (in->lambda_idx[i] < 0 || in->lambda_idx[i] >= scene->hdr.n_lambda) return fail(BMO_ERR_INVALID, "lambda_idx out of range");

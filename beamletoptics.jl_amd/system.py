@@ -482,22 +482,52 @@ def _trace_open_leaves(system, roots, r_max, device):
     while queue:  # BFS like solve_system!
         b = queue.pop(0)
         queue.extend(b.children)
-        if b.kind == bm.BEAM_GAUSSIAN:
-            raise NotImplementedError("solve_system(retrace=False) on solved GaussianBeamlets: the open-leaf continuation needs the beamlet's "
-                                      "accumulated lengths; retrace them (retrace=True) or release() and solve afresh")
         if b.rays[-1].intersection is None and len(b.rays) < r_max:
             open_beams.append(b)
     by_left = {}
     for b in open_beams:
         by_left.setdefault(r_max - len(b.rays) + 1, []).append(b)
     for left, group in sorted(by_left.items()):
+        gaussian = group[0].kind == bm.BEAM_GAUSSIAN
+        if gaussian and any(isinstance(o, cp.Photodetector) for o in system.objects()):
+            # the field of a beamlet on a Photodetector is evaluated on the device from ALL of its segments (bmo_photodetector_field); the
+            # continuation holds only those from the open ray on
+            raise NotImplementedError("solve_system(retrace=False) on solved GaussianBeamlets in a system with a Photodetector: retrace them "
+                                      "(retrace=True) or release() and solve afresh")
         heads = []
         for b in group:
-            last = b.rays[-1]
-            h = bm.Beam.__new__(bm.Beam)
-            h.rays, h.parent, h.children, h.status = [last], None, [], 0
+            if gaussian:
+                subs = []
+                for part in (b.chief, b.waist, b.divergence):
+                    sub = bm.Beam.__new__(bm.Beam)
+                    sub.rays, sub.parent, sub.children, sub.status = [part.rays[-1]], None, [], 0
+                    subs.append(sub)
+                h = bm.GaussianBeamlet(None, None, _parts=(subs[0], subs[1], subs[2], b.lam, b.w0, b.E0))
+                h.parent, h.children, h.status = None, [], 0
+            else:
+                h = bm.Beam.__new__(bm.Beam)
+                h.rays, h.parent, h.children, h.status = [b.rays[-1]], None, [], 0
             heads.append(h)
         bundle = bm.RayBundle.from_beams(heads)
+        if gaussian:
+            # the lengths the beamlets have accumulated up to their open rays (bmo.h "31 planes"), folded exactly as a solve that had
+            # never stopped would have folded them
+            acc = np.zeros((6, len(group)))
+            for i, b in enumerate(group):
+                l0 = 0.0 if b.parent is None else b.parent.length()
+                len_a, len_b = 0.0, l0
+                opl_c = 0.0 if b.chief.parent is None else b.chief.parent.optical_path_length()
+                for r in b.chief.rays[:-1]:
+                    len_a += r.intersection.t
+                    len_b += r.intersection.t
+                    opl_c += r.intersection.t * r.n
+                opl_w = opl_d = 0.0
+                for r in b.waist.rays[:-1]:
+                    opl_w += r.intersection.t * r.n
+                for r in b.divergence.rays[:-1]:
+                    opl_d += r.intersection.t * r.n
+                acc[:, i] = (len_a, len_b, l0, opl_c, opl_w, opl_d)
+            bundle = bm.RayBundle(bundle.kind, np.vstack([bundle.planes, acc]))
         scene = CompiledScene(system, bundle.lambdas)
         res, sol = _engine_solve(scene, bundle, left, None, device)
         # optical path length of each beam (parents included) up to the start of its open ray: what PSF records of the continuation add
@@ -508,8 +538,8 @@ def _trace_open_leaves(system, roots, r_max, device):
                 acc += r.optical_path_length()
             opl0.append(acc)
 
-        def hit_fix(slot, hits, res=res, scene=scene, opl0=opl0):
-            if scene.detectors[slot].kind != cp.O_PSF or not len(hits):
+        def hit_fix(slot, hits, res=res, scene=scene, opl0=opl0, gaussian=gaussian):
+            if gaussian or scene.detectors[slot].kind != cp.O_PSF or not len(hits):  # (a continued beamlet brings its path lengths along)
                 return hits
             hits = hits.copy()
             root_of_hit = res.node_root[res.detector_nodes(slot)]
@@ -519,7 +549,13 @@ def _trace_open_leaves(system, roots, r_max, device):
         _apply(scene, res, sol, heads, hit_fix)
         sol.free()
         for b, h in zip(group, heads):
-            b.rays[-1:] = h.rays  # the open ray (now with its intersection, if any) and what followed it
+            if gaussian:
+                for part, hp in ((b.chief, h.chief), (b.waist, h.waist), (b.divergence, h.divergence)):
+                    part.rays[-1:] = hp.rays
+                for c in h.children:
+                    c.chief.parent = b.chief  # parent! Gaussian.jl:113-117
+            else:
+                b.rays[-1:] = h.rays  # the open ray (now with its intersection, if any) and what followed it
             b.status = h.status
             for c in h.children:
                 c.parent = b

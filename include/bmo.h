@@ -198,11 +198,18 @@ enum bmo_beam_kind {
  *   POLARIZED  (14 planes): the 8 above, then Re(E0x) Im(E0x) Re(E0y) Im(E0y) Re(E0z) Im(E0z)
  *   GAUSSIAN   (25 planes): chief px..dz (6), waist px..dz (6), divergence px..dz (6),
  *                           lambda, n, w0, Re(E0), Im(E0), then 2 reserved (0)
+ *              (31 planes): the 25 above, then lenA lenB l0 oplC oplW oplD — the lengths a SOLVED beamlet has accumulated up to the
+ *                           segment this batch continues (solve_system!(...; retrace = false) on beamlets whose last ray is open,
+ *                           System.jl:449-458): lenA = sum of the chief's own earlier segment lengths folded from 0
+ *                           (length_rays, Beam.jl:160-169), lenB = the same fold started from l0, l0 = length(parent chief beam)
+ *                           (Beam.jl:125-130; 0 for a root), oplC = optical path of the chief, parents included, oplW / oplD =
+ *                           optical path of the waist / divergence beams' own earlier segments (Beam.jl:137-149)
  * dir must already be normalised by the caller exactly as the Ray constructor does
  * (Rays.jl:32-42); the engine does not renormalise first segments.               */
 #define BMO_PLANES_RAY 8
 #define BMO_PLANES_POLARIZED 14
 #define BMO_PLANES_GAUSSIAN 25
+#define BMO_PLANES_GAUSSIAN_CONTINUED 31
 
 typedef struct bmo_ray_batch {
     int64_t n;                  /* number of root beams                              */

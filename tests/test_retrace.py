@@ -292,3 +292,76 @@ def test_solve_again_without_retrace_traces_only_open_leaves():
                 assert ra.intersection.t == rb.intersection.t and type(ra.intersection.object) is type(rb.intersection.object)
     bmo.release(again)
     bmo.release(fresh)
+
+
+@pytest.mark.gpu
+def test_solve_again_without_retrace_continues_open_gaussian_beamlets():
+    """The same for GaussianBeamlets: the open beamlets (here: both children of a first splitter) are traced on as a batch that brings
+    their accumulated lengths along (bmo.h "31 planes": lenA, lenB, l0 and the three optical paths), so a SECOND splitter further on
+    sizes its children (w0, E0: gauss_parameters at the whole beamlet's length, ThinBeamsplitter.jl:117-168) and a PSFDetector records
+    the optical path of the whole beamlet exactly as in a solve that never stopped."""
+    import math
+
+    def build(stage):
+        bs1 = bmo.ThinBeamsplitter(20 * mm)
+        bmo.xrotate3d(bs1, math.radians(45))
+        bmo.translate3d(bs1, [0, 40 * mm, 0])
+        objs = [bs1]
+        if stage >= 1:
+            lens = bmo.SphericalLens(80 * mm, -80 * mm, 4 * mm, 25.4 * mm, 1.5)
+            bmo.translate3d(lens, [0, 90 * mm, 0])
+            bs2 = bmo.ThinBeamsplitter(20 * mm)
+            bmo.xrotate3d(bs2, math.radians(45))
+            bmo.translate3d(bs2, [0, 140 * mm, 0])
+            psf = bmo.PSFDetector(30 * mm)
+            bmo.translate3d(psf, [0, 200 * mm, 0])
+            objs += [lens, bs2, psf]
+        return bmo.System(objs)
+
+    def beamlets():
+        return [bmo.GaussianBeamlet([0.2 * mm * i, 0, 0.1 * mm * i], [0.0, 1, 0], 1064e-9, 0.4e-3, support=[1, 0, 0]) for i in range(-2, 3)]
+
+    fresh = beamlets()
+    sys_full = build(1)
+    for g in fresh:
+        bmo.solve_system(sys_full, g)
+    again = beamlets()
+    sys0 = build(0)
+    for g in again:
+        bmo.solve_system(sys0, g)
+        assert len(g.children) == 2 and all(c.rays[-1].intersection is None for c in g.children)  # both arms open
+    sys1 = build(1)
+    for g in again:
+        assert bmo.solve_system(sys1, g, retrace=False) is None
+
+    def same(a, b, path="root"):
+        assert a.w0 == b.w0 and a.E0 == b.E0, path
+        for pa, pb in ((a.chief, b.chief), (a.waist, b.waist), (a.divergence, b.divergence)):
+            assert len(pa.rays) == len(pb.rays), path
+            for ra, rb in zip(pa.rays, pb.rays):
+                assert np.array_equal(ra.pos, rb.pos) and np.array_equal(ra.dir, rb.dir) and ra.n == rb.n, path
+                assert (ra.intersection is None) == (rb.intersection is None), path
+                if ra.intersection is not None:
+                    assert ra.intersection.t == rb.intersection.t and np.array_equal(ra.intersection.n, rb.intersection.n), path
+        assert len(a.children) == len(b.children), path
+        for q, (ca, cb) in enumerate(zip(a.children, b.children)):
+            assert ca.parent is a and ca.chief.parent is a.chief
+            same(ca, cb, path + ".%d" % q)
+
+    deep = 0
+    for a, b in zip(again, fresh):
+        same(a, b)
+        deep += sum(len(c.children) for c in a.children)
+        assert a.length() == b.length() and all(ca.length() == cb.length() for ca, cb in zip(a.children, b.children))
+    assert deep > 0  # the second splitter was reached in the continuation and sized its children from the seeded lengths
+    psf_a, psf_b = sys1.objects()[-1], sys_full.objects()[-1]
+    assert len(psf_a.data) == len(psf_b.data) > 0 and np.array_equal(np.asarray(psf_a.data), np.asarray(psf_b.data))
+    # a system with a Photodetector is refused (its field needs every segment of the beamlet on the device)
+    pd = bmo.Photodetector(5 * mm, 16)
+    bmo.translate3d(pd, [0, 300 * mm, 0])
+    g = beamlets()[0]
+    bmo.solve_system(sys0, g)
+    with pytest.raises(NotImplementedError):
+        bmo.solve_system(bmo.System(sys0.objects() + [pd]), g, retrace=False)
+    for x in again + fresh + [g]:
+        bmo.release(x)
