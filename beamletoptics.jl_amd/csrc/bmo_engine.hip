@@ -1,17 +1,22 @@
 // bmo_engine.hip — MI355X (gfx950) trace engine behind the C ABI of include/bmo.h.
 //
 // Execution model: bounce-synchronous wavefront tracing.
-//   * One launch of step_kernel advances every ACTIVE beam node by one bounce
+//   * One launch of step_kernel advances every ACTIVE beam node by up to 32 bounces
 //     (tracing_step! + interact3d, System.jl:133-152).  Lane j works on record j of the
 //     current step chunk; the segment log IS the sequence of step chunks (SoA planes), so a
 //     bounce reads the 64 B it needs (pos, dir, n, hint) and writes intersection + next
-//     segment once — SURVEY.md §8d's 184 B/bounce.
+//     segment once — SURVEY.md §8d's 184 B/bounce.  Inside a launch a beam that goes on writes
+//     its next record in place (same slot of the next in-place chunk); every wave runs its
+//     own level loop and notes how far it got (Chunk::wl).
 //   * The scene tables (objects, shapes, triangles, n(lambda)) are staged into LDS by every
 //     workgroup; rays stay in HBM as structure-of-arrays planes (coalesced 8 B/lane loads).
+//     Shapes carry a class id: the lanes of a wave visit shapes of one class together, so the
+//     leaf switches branch on scalar compares (bmo_lane.hpp "wave-uniform control flow").
 //   * Survivors and beam-splitter children are compacted into the next chunk with a wave
-//     ballot + prefix popcount and ONE atomic per wave (child node ids likewise).
-//   * After the last step, nodes are put in the reference's order (bundle order x BFS order)
-//     by a radix sort on (root, depth, path) keys, and detector hits are compacted in that
+//     ballot + prefix popcount and ONE atomic per counter per workgroup (child node ids likewise).
+//   * After the last step, nodes are put in the reference's order (bundle order x BFS order):
+//     heap-index bitmaps per root for trees of up to 5 levels, a radix sort on (root, depth,
+//     path) keys up to 26, level-by-level ranking beyond; detector hits are compacted in that
 //     order (scan + gather) so the hit buffers equal the reference's push! order.
 // No CPU fallback: every entry point that traces requires a HIP device.
 #include <hip/hip_runtime.h>
