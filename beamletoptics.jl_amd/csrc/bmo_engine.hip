@@ -74,12 +74,14 @@ struct BlobHeader {
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
-    uint32_t has_asphere, pad;
+    uint32_t has_asphere, off_cands;
+    int32_t n_cands, pad[3];
 };
 
+// `h`: the blob's header; the kernels read it from their arguments (scalar loads the compiler may repeat instead of holding the
+// values in registers — read from the LDS copy they would sit in vector registers for the whole kernel)
 template <class CharPtr>
-__host__ __device__ inline SceneView view_of(CharPtr blob) {
-    auto h = (const BlobHeader*)(blob);
+__host__ __device__ inline SceneView view_of(CharPtr blob, const BlobHeader* h) {
     SceneView S;
     S.objects = (CObject*)(blob + h->off_objects);
     S.shapes = (CShape*)(blob + h->off_shapes);
@@ -87,6 +89,8 @@ __host__ __device__ inline SceneView view_of(CharPtr blob) {
     S.tris = (CDouble*)(blob + h->off_tris);
     S.n_table = (CDouble*)(blob + h->off_ntable);
     S.coefs = (CDouble*)(blob + h->off_coefs);
+    S.cands = (const BMO_KONST Cand*)(blob + h->off_cands);
+    S.n_cands = h->n_cands;
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -180,6 +184,7 @@ struct OldSolution {
 #endif
 constexpr int MAX_FUSE = BMO_MAX_FUSE;
 struct StepParams {
+    BlobHeader hdr;  // copy of the scene blob's header
     const char* blob;
     uint32_t blob_bytes;
     int32_t use_lds;
@@ -281,7 +286,8 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
 }
 
 #ifndef BMO_MIN_WAVES
-#define BMO_MIN_WAVES 2  /* <= 256 VGPRs: 2 waves/SIMD measured 1.4x faster than 1; 4 (128 VGPRs) spills */
+#define BMO_MIN_WAVES 3  /* <= 168 VGPRs.  Round 3: with the scene tables read by scalar loads tracing_step is spill-free at 168 registers and 3 waves/SIMD
+                            beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5 (profiles/r03_ab_scalar_scene.txt); 4 (128) still spills in the march */
 #endif
 // Scene access: the LDS variant derives every table pointer from the __shared__ array so the compiler emits
 // ds_read (a run-time select between an LDS and a global pointer degrades ALL table reads to flat_load: measured
@@ -294,9 +300,9 @@ __device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds)
         uint4* dst = reinterpret_cast<uint4*>(lds);
         for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
         __syncthreads();
-        return view_of((const char*)lds);
+        return view_of((const char*)lds, &P.hdr);
     } else {
-        return view_of((const char*)P.blob);
+        return view_of((const char*)P.blob, &P.hdr);
     }
 }
 
@@ -411,6 +417,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             } else {
                 // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
                 ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+                const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
 #if defined(BMO_DEV_TIMELINE)
                 {
                     const unsigned long long t = wall_clock64();
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     tk_last = t;
                 }
 #endif
-                X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, ho, hs, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, ho, hs, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
 #if defined(BMO_DEV_TIMELINE)
                 {
                     const unsigned long long t = wall_clock64();
@@ -667,11 +674,12 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             rec.clear_hits();
         } else {
             ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+            const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
             if (RETR && no_hint) {
                 GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node}};
-                gauss_step_rec<ASPH, RETR>(S, rn, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                gauss_step_rec<ASPH, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             } else {
-                gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             }
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
@@ -1499,36 +1507,31 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     lap("setup");
     const uint32_t blob_bytes = (uint32_t)scene->blob.size();
-    const int use_lds = (blob_bytes <= 120 * 1024 && !getenv("BMO_NO_LDS")) ? 1 : 0;
+    // the scene tables stay in global memory: the kernels read them with scalar loads through constant-address-space pointers
+    // (bmo_lane.hpp "scalar scene access"); LDS holds the per-lane columns only
+    const int use_lds = 0;
     DBG("roots initialised n=%lld blob=%u use_lds=%d", (long long)n, blob_bytes, use_lds);
     if (dbg_on()) {
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         DBG("init kernel done");
     }
-    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)BMO_CC_MAX * BMO_BLOCK * 8;  // + block_alloc scratch + child cache columns
+    // + block_alloc scratch + per-lane columns: child cache (BMO_CC_MAX doubles) and the lane memory of tracing_step (BMO_LANE_MEM doubles)
+    const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)(BMO_CC_MAX + BMO_LANE_MEM) * BMO_BLOCK * 8;
     void (*kern)(StepParams) = nullptr;
     const bool asph = scene->hdr.has_asphere != 0;
 #if defined(BMO_DEV_RAY_LDS_ONLY)  // developer build (kernel work on one variant): everything else is refused, nothing falls back
     if constexpr (KIND == BMO_BEAM_RAY) {
-        if (!prev && use_lds && !asph) kern = &step_kernel<BMO_BEAM_RAY, true, false, false>;
+        if (!prev && !asph) kern = &step_kernel<BMO_BEAM_RAY, false, false, false>;
     }
-    if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY, LDS> is compiled in");
+    if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY> is compiled in");
 #else
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
-        if (prev)
-            kern = use_lds ? (asph ? &step_kernel_gauss<true, true, true> : &step_kernel_gauss<true, false, true>)
-                           : (asph ? &step_kernel_gauss<false, true, true> : &step_kernel_gauss<false, false, true>);
-        else
-            kern = use_lds ? (asph ? &step_kernel_gauss<true, true, false> : &step_kernel_gauss<true, false, false>)
-                           : (asph ? &step_kernel_gauss<false, true, false> : &step_kernel_gauss<false, false, false>);
+        if (prev) kern = asph ? &step_kernel_gauss<false, true, true> : &step_kernel_gauss<false, false, true>;
+        else kern = asph ? &step_kernel_gauss<false, true, false> : &step_kernel_gauss<false, false, false>;
     } else {
-        if (prev)
-            kern = use_lds ? (asph ? &step_kernel<KIND, true, true, true> : &step_kernel<KIND, true, false, true>)
-                           : (asph ? &step_kernel<KIND, false, true, true> : &step_kernel<KIND, false, false, true>);
-        else
-            kern = use_lds ? (asph ? &step_kernel<KIND, true, true, false> : &step_kernel<KIND, true, false, false>)
-                           : (asph ? &step_kernel<KIND, false, true, false> : &step_kernel<KIND, false, false, false>);
+        if (prev) kern = asph ? &step_kernel<KIND, false, true, true> : &step_kernel<KIND, false, false, true>;
+        else kern = asph ? &step_kernel<KIND, false, true, false> : &step_kernel<KIND, false, false, false>;
     }
 #endif
     if (lds_bytes > 48 * 1024)
@@ -1581,6 +1584,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
         if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
         StepParams P;
+        P.hdr = scene->hdr;
         P.blob = dblob;
         P.blob_bytes = blob_bytes;
         P.use_lds = use_lds;
@@ -2029,6 +2033,9 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     off = al(off + 8 * (size_t)std::max(1, d->n_media) * (size_t)d->n_lambda);
     h.off_coefs = (uint32_t)off;
     off = al(off + 8 * (size_t)std::max(1, d->n_coefs));
+    h.off_cands = (uint32_t)off;
+    h.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, nullptr);
+    off = al(off + sizeof(Cand) * (size_t)std::max(1, h.n_cands));
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -2046,29 +2053,11 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
             sh->tri_begin = d->children[sh->child_begin];
         }
     }
-    {   // shape classes (bmo_lane.hpp "wave-uniform control flow"): equal class <=> same code path with different numbers
-        bmo_shape* shp = reinterpret_cast<bmo_shape*>(sc->blob.data() + h.off_shapes);
-        std::map<std::vector<int32_t>, int32_t> ids;
-        std::vector<int32_t> cls((size_t)d->n_shapes, 0);
-        auto pass = [&](auto&& wanted) {
-            for (int i = 0; i < d->n_shapes; ++i) {
-                const bmo_shape& sh = shp[i];
-                if (!wanted(sh.kind)) continue;
-                std::vector<int32_t> sig{sh.kind, sh.flags & ((1 << BMO_SHAPE_CLASS_SHIFT) - 1), sh.kind == BMO_SHAPE_MESH ? sh.tri_count : sh.child_count};
-                if (sh.kind == BMO_SHAPE_UNION || sh.kind == BMO_SHAPE_MENISCUS)
-                    for (int c = 0; c < sh.child_count; ++c) sig.push_back(cls[(size_t)d->children[sh.child_begin + c]]);
-                cls[(size_t)i] = ids.emplace(sig, (int32_t)ids.size()).first->second;
-            }
-        };
-        pass([](int k) { return k != BMO_SHAPE_UNION && k != BMO_SHAPE_MENISCUS; });  // leaves first: a meniscus has leaf children,
-        pass([](int k) { return k == BMO_SHAPE_MENISCUS; });                            // a union leaf or meniscus children
-        pass([](int k) { return k == BMO_SHAPE_UNION; });
-        for (int i = 0; i < d->n_shapes; ++i) shp[i].flags = (shp[i].flags & ((1 << BMO_SHAPE_CLASS_SHIFT) - 1)) | (cls[(size_t)i] << BMO_SHAPE_CLASS_SHIFT);
-    }
     if (d->n_children) std::memcpy(sc->blob.data() + h.off_children, d->children, 4 * (size_t)d->n_children);
     if (d->n_tris) std::memcpy(sc->blob.data() + h.off_tris, d->tris, 72 * (size_t)d->n_tris);
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
+    fill_candidates(d->objects, d->n_objects, d->shapes, reinterpret_cast<Cand*>(sc->blob.data() + h.off_cands));  // trace_all's flat slot list
     sc->hdr = h;
     *out = sc.release();
     return BMO_OK;

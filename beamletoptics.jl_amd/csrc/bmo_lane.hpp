@@ -44,31 +44,42 @@ namespace bmo {
 inline long g_emu_sdf_any = 0, g_emu_sdf_leaf = 0, g_emu_normal = 0, g_emu_normal_fd = 0;
 #endif
 
-// Wave-uniform control flow (device builds; -DBMO_DIVERGENT_CTRL restores per-lane control flow for A/B runs).
-// The engine gives every shape a CLASS (bits 8.. of its copy of `flags`): two shapes are of one class when they have the same kind,
-// flags and child / triangle / coefficient count and their children are pairwise of one class — i.e. when evaluating them runs
-// the same code with different numbers.  The lanes of a wave visit the shapes of one class together ("waterfall": one pass per
-// distinct class among the active lanes, tracing_step / normal_any), so inside a pass everything that steers control flow — kinds,
-// counts, flags — has the same value in every active lane although the table entries (positions, radii, ...) stay per lane.
-// BMO_UNIFORM(x) marks such a value: the compiler then branches on it with scalar compares instead of building execution masks
-// for every `switch (kind)` (the leaf switches are most of the kernel's control flow).  Host builds: the identity.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BMO_DIVERGENT_CTRL)
+// Scalar scene access (device builds).  The scene tables (objects, shapes, children, triangles, n(lambda), candidate table) are
+// read-only for the life of a kernel and sit in global memory behind CONSTANT-address-space pointers (CShape, CObject, CDouble, CInt,
+// CCand below): a read whose index is the same in all lanes of the wave then compiles to a scalar load (s_load, served by the scalar
+// cache) and its value lives in scalar registers — the FP64 vector instructions take it as an operand directly, no vector register and
+// no LDS round trip per table entry.  BMO_UNIFORM(i) (readfirstlane) marks such an index.  The wave therefore works on ONE shape at a
+// time: the slots of trace_all are wave-uniform by construction (the candidate table is walked by a scalar loop); where lanes can
+// disagree — the hinted shape of trace_one, the shape that won the step, the arg-min child of a union whose normal is needed — the
+// lanes are taken through a "waterfall": one pass per distinct id among the active lanes (one pass in a coherent wave).  A read with a
+// per-lane index through the same pointers is an ordinary vector load (interact3d's look-up of the object that was hit).
+// Host builds (emulator, sanitizers): plain pointers, BMO_UNIFORM is the identity and every waterfall has one lane and one pass.
+#if defined(__HIP_DEVICE_COMPILE__)
 #define BMO_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
-#define BMO_WATERFALL 1
+#define BMO_KONST __attribute__((address_space(4)))
+// Waterfall test "is this lane's id the one the wave works on now": the scalar id goes through an empty asm so that the optimiser does
+// not learn `u == id` inside the branch and substitute the per-lane id back for the scalar one (its reads would turn into vector loads).
+__device__ __forceinline__ bool bmo_same_id(int32_t u, int32_t id) {
+    asm volatile("" : "+s"(u));
+    return u == id;
+}
 #else
 #define BMO_UNIFORM(i) (i)
+#define BMO_KONST
+inline bool bmo_same_id(int32_t u, int32_t id) { return u == id; }
 #endif
-#define BMO_SHAPE_CLASS_SHIFT 8  // engine-private bits of bmo_shape.flags in the device copy of the scene
-// BMO_WAVE_ALL(p): true when p holds in every lane of the wave that executes this statement (host: the lane itself)
+// BMO_WAVE_ALL(p) / BMO_WAVE_ANY(p): p holds in every / some lane of the wave that executes this statement (host: the lane itself)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BMO_WAVE_ALL(p) (__all(p) != 0)
+#define BMO_WAVE_ANY(p) (__any(p) != 0)
 #else
 #define BMO_WAVE_ALL(p) (p)
+#define BMO_WAVE_ANY(p) (p)
 #endif
-typedef const bmo_shape CShape;
-typedef const bmo_object CObject;
-typedef const double CDouble;
-typedef const int32_t CInt;
+typedef const BMO_KONST bmo_shape CShape;
+typedef const BMO_KONST bmo_object CObject;
+typedef const BMO_KONST double CDouble;
+typedef const BMO_KONST int32_t CInt;
 
 
 struct SceneView {
@@ -78,7 +89,8 @@ struct SceneView {
     CDouble* tris;
     CDouble* n_table;
     CDouble* coefs;
-    int32_t n_objects, n_lambda;
+    const BMO_KONST struct Cand* cands;  // candidate table (fill_candidates)
+    int32_t n_objects, n_lambda, n_cands;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int32_t march_iters;
 };
@@ -114,19 +126,21 @@ BMO_HD double jmin_rule(double x, double y) {
     if (isnan_(x) || isnan_(y)) return x + y;
     return ((y < x) || (sgn(y) > sgn(x))) ? y : x;
 }
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BMO_HW_MINMAX)
-// Optional device form (-DBMO_HW_MINMAX): v_max_f64 / v_min_f64 order the zeros the same way (+0 > -0) and return the other operand for
-// a NaN, so one NaN select on top gives the rule without control flow (the rule form compiles to execution-mask branches).  Measured:
-// -1.5 % on config 5, -2 % on the vignetted bundle, +1 % on config 2 at first (profiles/r02_ab_minmax_forms.txt), +4 % on config 2 and
-// +1 % on config 5 on the round's final code (profiles/r02_ab_uniform_ctrl.txt) — not the default;
-// bmo_selftest compares whichever form is compiled in with the rule, bit for bit on the special values, on the device.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BMO_RULE_MINMAX)
+// Device form: v_max_f64 / v_min_f64 order the zeros the same way (+0 > -0) and return the other operand for a NaN, so one NaN select
+// (x + y is NaN exactly when x or y is) on top gives the rule without control flow: 5 instructions, where the rule form compiles to
+// compare-and-branch sequences with execution-mask bookkeeping.  The instruction is written out because __builtin_fmax first
+// canonicalises both operands (two more v_max_f64).  bmo_selftest compares this form with the rule, bit for bit on the special values,
+// on the device.  -DBMO_RULE_MINMAX builds the rule form for A/B runs.
 BMO_HD double jmax(double x, double y) {
-    const double m = __builtin_fmax(x, y);
-    return (isnan_(x) | isnan_(y)) ? x + y : m;
+    double m;
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    return __builtin_isunordered(x, y) ? x + y : m;
 }
 BMO_HD double jmin(double x, double y) {
-    const double m = __builtin_fmin(x, y);
-    return (isnan_(x) | isnan_(y)) ? x + y : m;
+    double m;
+    asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    return __builtin_isunordered(x, y) ? x + y : m;
 }
 #else
 BMO_HD double jmax(double x, double y) { return jmax_rule(x, y); }
@@ -498,25 +512,23 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
     return T{} + kinf();
 }
 
-// leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46): one loop so the leaf switch is inlined once
+// leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46: max(min(convex, cylinder), -concave) in the meniscus frame): one loop so the leaf
+// switch is inlined once; the three leaf values are folded as they come (one running value live, not three)
 template <class T, bool ASPH>
 BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
     const int kind0 = BMO_UNIFORM(s.kind);
     const bool men = kind0 == BMO_SHAPE_MENISCUS;
-    v3<T> p = pt;
-    if (men) p = to_local(s, pt);
     const int nleaf = men ? 3 : 1;
-    T a = T{}, b = T{}, c = T{};
+    T acc = T{};
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
         CShape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
-        T v = sdf_leaf<T, ASPH>(leaf, men ? BMO_UNIFORM(leaf.kind) : kind0, p, S.coefs);
-        if (q == 0) a = v;
-        else if (q == 1) b = v;
-        else c = v;
+        const T v = sdf_leaf<T, ASPH>(leaf, men ? BMO_UNIFORM(leaf.kind) : kind0, men ? to_local(s, pt) : pt, S.coefs);
+        if (q == 0) acc = v;
+        else if (q == 1) acc = jmin(acc, v);
+        else acc = jmax(acc, -v);
     }
-    if (men) return jmax(jmin(a, b), -c);
-    return a;
+    return acc;
 }
 
 // Per-lane memory of the child values of ONE union along ONE march (device: a column of LDS, host emulator: a local array).
@@ -680,26 +692,21 @@ BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
     }
     return normalize_div(d3{g0, g1, g2});
 }
-// normal3d of shape `sid` (table entry `s`) or, for a UnionSDF, of its arg-min child
+// normal3d of shape `sid` or, for a UnionSDF, of its arg-min child (UnionSDF.jl:86-91); `kind`, `child_begin`: the shape's table fields.
+// The arg-min children of the lanes may differ: one pass per distinct shape among them (scalar scene access, file header).
 template <bool ASPH>
-BMO_HD d3 normal_any(const SceneView& S, int32_t sid, const ShapeHead& H, const d3& p, int32_t best_child) {
+BMO_HD d3 normal_at(const SceneView& S, int32_t sid, int32_t kind, int32_t child_begin, const d3& p, int32_t best_child) {
     int32_t tid = sid;
-    if (H.kind == BMO_SHAPE_UNION) tid = S.children[H.child_begin + best_child];
-#if defined(BMO_WATERFALL)
-    // one pass per distinct class among the lanes' shapes (the arg-min children of a union may be of different kinds)
+    if (kind == BMO_SHAPE_UNION) tid = S.children[child_begin + best_child];
     d3 n{0, 0, 0};
-    const int32_t cls = S.shapes[tid].flags >> BMO_SHAPE_CLASS_SHIFT;
-    for (bool pending = true; pending;) {
-        const int32_t u = __builtin_amdgcn_readfirstlane(cls);
-        if (u == cls) {
-            n = normal_of<ASPH>(S, S.shapes[tid], p);
-            pending = false;
+    for (bool todo = true; todo;) {
+        const int32_t u = BMO_UNIFORM(tid);
+        if (bmo_same_id(u, tid)) {
+            n = normal_of<ASPH>(S, S.shapes[u], p);
+            todo = false;
         }
     }
     return n;
-#else
-    return normal_of<ASPH>(S, S.shapes[tid], p);
-#endif
 }
 
 // ------------------------------------------------------------------ miss cull (see file header)
@@ -746,251 +753,371 @@ BMO_HD double moeller_trumbore(CDouble* f, const d3& pos, const d3& dir, double 
     return t;
 }
 
-// intersect3d(shape, ray).
-//   Mesh: Mesh.jl:244-267.
-//   SDF:  AbstractSDF.jl:166-181 with _raymarch_outside (:102-125) and _raymarch_inside (:132-159)
-//         run as ONE state machine around one SDF evaluation per iteration:
-//           CLASSIFY: d = sdf(p0); d > eps_srf -> OUT(dir) ; else normal test -> IN or `nothing`
-//           IN:  p += eps_ins*dir, t_in += eps_ins; sdf(p) > 0 -> OUT(-dir) from here (dist = that sdf)
-//           OUT: p += dist*dir', dist = sdf(p), t0 += dist, hit when dist < eps_ray
-//         The reference's _raymarch_outside re-evaluates sdf at its start point; that value equals the
-//         one just computed at the same point, so it is reused (bit-identical, one evaluation less).
-//   `t_limit`: a hit whose t exceeds it cannot win trace_all's strict `<` selection (System.jl:67), so the
-//   outside march stops once its running t0 exceeds it.  t0 only grows by positive steps until the final
-//   sub-tolerance step (>= -1e-8*dist for these 1-Lipschitz SDFs), so with the caller's 1e-6 margin the
-//   pruned shape is provably a loser; results are unchanged (DESIGN.md "nearest-hit prune").
-template <bool ASPH>
-BMO_HD Hit intersect_shape(const SceneView& S, int32_t sid, const d3& pos0, const d3& dir0, double t_limit, ChildCache& cc) {
-    CShape& s = S.shapes[sid];
-    Hit h = no_hit();
-    {
-        const double t_lb = cull_entry(s, pos0, dir0);
-        if (t_lb < 0.0) return h;                            // provable `nothing`
-        if (t_lb * (1.0 - 1e-9) - 1e-9 > t_limit) return h;  // provable loser of the nearest-hit selection
-    }
-    const ShapeHead H = shape_head(s);
-    if (H.kind == BMO_SHAPE_MESH) {
-        int fid = -1;
-        double t0 = kinf();
-        const int ntri = BMO_UNIFORM(s.tri_count), tri0 = H.tri_begin;
-        BMO_NOUNROLL
-        for (int i = 0; i < ntri; ++i) {
-            double t = moeller_trumbore(S.tris + 9 * (tri0 + i), pos0, dir0, S.mt_keps, S.mt_leps);
-            if (t < t0) {
-                t0 = t;
-                fid = i;
-            }
+// intersect3d(mesh, ray) Mesh.jl:244-267: nearest face with strict `<` (the first face wins ties).  Returns t (inf: none) and the face.
+BMO_HD double mesh_nearest(const SceneView& S, int tri0, int ntri, const d3& pos, const d3& dir, int32_t& fid) {
+    double t0 = kinf();
+    fid = -1;
+    BMO_NOUNROLL
+    for (int i = 0; i < ntri; ++i) {
+        const double t = moeller_trumbore(S.tris + 9 * (tri0 + i), pos, dir, S.mt_keps, S.mt_leps);
+        if (t < t0) {
+            t0 = t;
+            fid = i;
         }
-        if (fid < 0) return h;
-        CDouble* f = S.tris + 9 * (tri0 + fid);
-        d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
-        d3 n = normalize_div(cross3(sub3(V2, V1), sub3(V3, V1)));  // normal3d(mesh, fID) Mesh.jl:183-192
-        h.t = t0;
-        h.n = normalize_div(n);  // second normalize, Mesh.jl:265
-        h.shape = sid;
-        return h;
     }
-    enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2 };
-    const bool exact = !(H.flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
-    int phase = CLASSIFY;
-    d3 pos = pos0, dir = dir0;
-    double dist = 0.0, t0 = 0.0, t_in = 0.0;
-    int i_out = 1, i_in = 1;
-    bool back = false;
-    // `pending`: this lane stands on the surface (start classification) or has converged (hit) and needs a normal.  The normal
-    // (dual-number gradient, by far the most expensive piece) is evaluated only when EVERY lane of the wave still inside this
-    // loop is pending, so the wave runs that code once per round instead of once per iteration in which some lane converges.
-    // Pure scheduling: each lane's arithmetic and its order are untouched (on the host emulator the vote is the lane itself).
-    bool pending = false;
-    int32_t bc = 0;
-    double d = 0.0;
-    child_cache_reset(cc);
-    for (;;) {
-        if (!pending) {
-            double moved = 0.0;  // how far this iteration moved the evaluation point (Lipschitz memory of the union children)
-            if (phase == INSIDE) {
-                pos = axpy3(pos, S.eps_ins, dir);
-                t_in += S.eps_ins;
-                moved = S.eps_ins;
-            } else if (phase == OUTSIDE) {
-                pos = axpy3(pos, dist, dir);
-                moved = fabs(dist);
-            }
-            d = sdf_any<ASPH>(S, H, s, pos, bc, cc, moved);
-            bool give_up = false;  // the reference returns `nothing` here
-            if (phase == CLASSIFY) {
-                if (d > S.eps_srf) {
-                    phase = OUTSIDE;
-                    dist = d;
-                    t0 = d;
-                    i_out = 1;
-                    give_up = !(i_out <= S.march_iters) || (exact && t0 > t_limit);
-                } else {
-                    pending = true;
-                }
-            } else if (phase == INSIDE) {
-                if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
-                    phase = OUTSIDE;
-                    back = true;
-                    dir = neg3(dir);
-                    dist = d;
-                    t0 = d;
-                    i_out = 1;
-                    give_up = !(i_out <= S.march_iters);
-                } else {
-                    i_in += 1;
-                    give_up = !(i_in <= S.march_iters);
-                }
-            } else {
-                dist = d;
-                t0 += d;
-                i_out += 1;
-                if (d < S.eps_ray) {
-                    pending = true;
-                } else {
-                    // (read here, every iteration: holding the sphere in registers across the march costs more in spills — +2.5 % — than
-                    // the two LDS reads)
-                    const BoundSphere bs{s.bs_center[0], s.bs_center[1], s.bs_center[2], s.bs_radius};
-                    give_up = cull_receding(bs, pos, dir)               // provable miss: skip the rest of the 1000 evaluations
-                              || (exact && !back && t0 > t_limit)       // provable loser of the nearest-hit selection
-                              || !(i_out <= S.march_iters);
-                }
-            }
-            if (give_up) return h;
-        }
-        if (!BMO_WAVE_ALL(pending)) continue;
-        pending = false;
-        // single normal evaluation site: the reference's normal3d, for the start classification on the surface
-        // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the hit
-        const d3 n = normal_any<ASPH>(S, sid, H, pos, bc);
-        if (phase == CLASSIFY) {
-            if (dot3(dir, n) <= 0) {  // entering
-                phase = INSIDE;
-                t_in = 0.0;
-                i_in = 1;
-                if (!(i_in <= S.march_iters)) return h;
-                continue;
-            }
-            return h;  // on the surface and leaving: no intersection
-        }
-        h.t = back ? t_in - t0 : t0;
-        h.n = n;
-        h.shape = sid;
-        return h;
-    }
+    return t0;
+}
+// normal3d(mesh, fID) Mesh.jl:183-192, normalised a second time by intersect3d (Mesh.jl:265)
+BMO_HD d3 mesh_normal(const SceneView& S, int tri) {
+    CDouble* f = S.tris + 9 * tri;
+    d3 V1{f[0], f[1], f[2]}, V2{f[3], f[4], f[5]}, V3{f[6], f[7], f[8]};
+    d3 n = normalize_div(cross3(sub3(V2, V1), sub3(V3, V1)));
+    return normalize_div(n);
 }
 
-// tracing_step! (System.jl:100-110) = trace_one (:74-85) falling back to trace_all (:57-72), written as
-// one loop over "slots": slot -1 is the hinted SHAPE (if any), slots 0..M-1 are the leaf objects.
-// Object-level rules: SingleShape/MultiShape AbstractRay.jl:118-155, plate splitter
-// PlateBeamsplitter.jl:160-187, NonInteractable.jl:19.  `calls` counts the reference's intersect3d calls.
-//
-// RETR builds add the probe of retrace_system! (System.jl:208-218) as a first pass over the same slot loop (so the big
-// intersect_shape body keeps its single call site): with `probe` set, pass 0 tests only the hinted shape
-// (intersect3d(shape(_hint), ray)) or, without a hint, only the object of the stored intersection
-// (intersect3d(object(_intersection), ray)); a probe miss is the reference's cleanup path, after which solve_leaf!
-// traces the same ray on WITHOUT a hint (System.jl:130-133) if `fresh_allowed` (length(rays) < r_max).
-template <bool ASPH, bool RETR = false>
-BMO_HD Hit tracing_step(const SceneView& S, const d3& pos, const d3& dir, int32_t hint_obj, int32_t hint_shape, uint32_t& calls, ChildCache& cc,
-                        bool probe = false, int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
-    Hit X = no_hit();
-    bool done = false;
-    int32_t skip_obj = -1;            // object already tested by the probe with this very ray (pure function => same `nothing`)
-    int32_t tested_shape = -1;        // shape tested in slot -1 (or by the probe) with this very ray
-    BMO_NOUNROLL
-    for (int pass = (RETR && probe) ? 0 : 1; pass < 2 && !done; ++pass) {
-        int32_t hs = hint_shape;  // shape tested in slot -1 of this pass (-1: none)
-        int o_lo = 0, o_hi = S.n_objects;
-        bool fall_back = true;    // slot -1 missed: go on with the object slots (trace_one -> trace_all)
-        if (RETR && pass == 0) {
-            calls += 1;
-            if (hint_shape >= 0) {
-                o_hi = 0;
-                fall_back = false;
-            } else {
-                o_lo = probe_obj;
-                o_hi = probe_obj + 1;
+// One entry of the candidate table: the parts of the leaf objects in the reference's order (objects in Leaves order, parts in the
+// order intersect3d(object, ray) visits them; a plate splitter's coating before its substrate, PlateBeamsplitter.jl:160-187;
+// NonInteractable objects have none, NonInteractable.jl:19), each with its shape's bounding sphere.  Built once per scene
+// (fill_candidates below) so that trace_all (System.jl:57-72) is one flat loop over 48-byte records instead of a nest over
+// objects and parts with table look-ups at every level.
+struct Cand {
+    double cx, cy, cz, R;  // bs_center / bs_radius of the part's shape
+    int32_t sid, obj;
+    int32_t info;          // bit 0: the part is the substrate of a plate splitter (tested after its coating); bit 1: its coating
+    int32_t pad;
+};
+enum { CAND_PLATE_SUBSTRATE = 1, CAND_PLATE_COATING = 2 };
+// number of candidates of a scene / the table itself (host side, at scene creation; `out` may be null to count)
+inline int fill_candidates(const bmo_object* objects, int n_objects, const bmo_shape* shapes, Cand* out) {
+    int n = 0;
+    for (int o = 0; o < n_objects; ++o) {
+        const bmo_object& ob = objects[o];
+        int np = (ob.kind == BMO_OBJ_DOUBLET) ? 2 : (ob.kind == BMO_OBJ_CUBE_BS ? 3 : (ob.kind == BMO_OBJ_PLATE_BS ? 2 : 1));
+        if (ob.kind == BMO_OBJ_NONINTERACTABLE) np = 0;
+        for (int k = 0; k < np; ++k) {
+            int32_t sid = ob.shape[k];
+            int32_t info = 0;
+            if (ob.kind == BMO_OBJ_PLATE_BS) {  // coating (shape[1]) first, then substrate (shape[0])
+                sid = ob.shape[1 - k];
+                info = k == 0 ? CAND_PLATE_COATING : CAND_PLATE_SUBSTRATE;
             }
-        } else if (RETR && probe) {  // the probe missed
-            if (probe_missed) *probe_missed = true;
-            if (!fresh_allowed) break;
-            if (hint_shape < 0) skip_obj = probe_obj;
-            hs = -1;
-            calls += (uint32_t)S.n_objects;
-        } else {
-            calls += hs >= 0 ? 1u : (uint32_t)S.n_objects;
+            if (out) {
+                const bmo_shape& sh = shapes[sid];
+                out[n] = Cand{sh.bs_center[0], sh.bs_center[1], sh.bs_center[2], sh.bs_radius, sid, o, info, 0};
+            }
+            ++n;
         }
-        if (hs >= 0) tested_shape = hs;
-        BMO_NOUNROLL
-        for (int o = -1; o < o_hi; ++o) {  // the induction variable stays wave-uniform; lanes skip the slots they do not use
-            if (o < 0 ? hs < 0 : (o < o_lo || o == skip_obj)) continue;
-            int kind = BMO_OBJ_INTERSECTABLE, np = 1;
-            int32_t sh0 = hs, sh1 = -1, sh2 = -1;
-            if (o >= 0) {
-                CObject& ob = S.objects[BMO_UNIFORM(o)];
-                kind = BMO_UNIFORM(ob.kind);
-                sh0 = BMO_UNIFORM(ob.shape[0]);
-                sh1 = BMO_UNIFORM(ob.shape[1]);
-                sh2 = BMO_UNIFORM(ob.shape[2]);
-                np = (kind == BMO_OBJ_DOUBLET) ? 2 : (kind == BMO_OBJ_CUBE_BS ? 3 : (kind == BMO_OBJ_PLATE_BS ? 2 : 1));
-                if (kind == BMO_OBJ_NONINTERACTABLE) np = 0;
-                if (kind == BMO_OBJ_PLATE_BS) {  // coating first, then substrate
-                    int32_t t = sh0;
-                    sh0 = sh1;
-                    sh1 = t;
+    }
+    return n;
+}
+
+// Per-lane memory of one tracing step besides the child cache (device: columns of LDS, host: a local array), m[c * stride]:
+//   0..2  end point of the march that produced the best hit so far; after the step: the normal of the winning hit
+//   3..5  origin of the ray (re-read where a candidate is set up instead of being held in registers across the marches)
+//   6     PLATE_BS: t of the coating's hit
+// The normal of a hit is evaluated once, for the hit that wins the tracing step (see tracing_step).
+constexpr int BMO_LANE_MEM = 7;
+struct LaneMem {
+    double* m;
+    int stride;
+    BMO_HD d3 get3(int c) const { return d3{m[c * stride], m[(c + 1) * stride], m[(c + 2) * stride]}; }
+    BMO_HD void put3(int c, const d3& v) const {
+        m[c * stride] = v.x;
+        m[(c + 1) * stride] = v.y;
+        m[(c + 2) * stride] = v.z;
+    }
+};
+
+// the `nothing` decisions of cull_entry without its square root: the line misses the (inflated) bounding sphere, or the origin is
+// outside it and receding
+BMO_HD bool cull_miss(double cx, double cy, double cz, double R, const d3& pos, const d3& dir) {
+    if (!(R >= 0.0)) return false;
+    const d3 oc{cx - pos.x, cy - pos.y, cz - pos.z};
+    const double dd = dot3(dir, dir), b = dot3(oc, dir), cc = dot3(oc, oc), R2 = R * R;
+    if (!(cc > R2)) return false;
+    if (b < 0.0) return true;
+    return b * b - dd * (cc - R2) < 0.0;
+}
+
+// tracing_step! (System.jl:100-110) = trace_one (:74-85) falling back to trace_all (:57-72), with intersect3d of objects
+// (SingleShape / MultiShape AbstractRay.jl:118-155, plate splitter PlateBeamsplitter.jl:160-187, NonInteractable.jl:19), of meshes
+// (Mesh.jl:244-267) and of SDF shapes (AbstractSDF.jl:166-181 with _raymarch_outside :102-125 and _raymarch_inside :132-159) written as
+// ONE flat nest of wave-uniform loops around one SDF evaluation site and one normal site:
+//
+//   pass   0 (RETR builds): the probe of retrace_system! (System.jl:208-218) — only the hinted shape, or without a hint only the object
+//            of the stored intersection; a probe miss is the reference's cleanup path, after which solve_leaf! traces the same ray on
+//            WITHOUT a hint (System.jl:130-133) if `fresh_allowed` (length(rays) < r_max);
+//          1 trace_one / trace_all;   2 the normal of the winning hit.
+//   slot   -1 the hinted SHAPE (if any), 0..NC-1 the candidate table (parts of the leaf objects in the reference's order).  Before
+//          slot 0 every lane that goes on to trace_all collects the candidates it has to march in a bit mask (`cull_miss` against the
+//          bounding spheres: one tight loop over the table), so that the slots themselves only visit what some lane needs.
+//   round  march loop, then the normal site for the lanes that wait for one, at most twice:
+//   march  per lane a state machine around one sdf evaluation per trip:
+//            CLASSIFY: d = sdf(p0); d > eps_srf -> OUTSIDE; else the lane waits for the normal site -> INSIDE or `nothing`
+//            INSIDE:   p += eps_ins*dir, t_in += eps_ins; sdf(p) > 0 -> OUTSIDE backwards from here (dist = that sdf)
+//            OUTSIDE:  p += dist*dir', dist = sdf(p), t0 += dist, hit when dist < eps_ray
+//          The reference's _raymarch_outside re-evaluates sdf at its start point; that value equals the one just computed at the same
+//          point, so it is reused (bit-identical, one evaluation less).  The backward march uses p + (-dist)*dir, which is bit for bit
+//          p + dist*(-dir) (IEEE negation is exact and commutes with rounding).
+//
+// What differs from the reference's evaluation ORDER, never from its results:
+//   * A hit is folded into the running best at once (strict `<` over slots in the reference's order keeps the first of equal
+//     minima, which is what the reference's two-level fold — parts, then objects — keeps; the plate splitter's coating-wins-ties rule
+//     needs the coating's t while the substrate is marched: lane memory 6).
+//   * normal3d is a pure function of (shape, point): the reference evaluates it for every hit, here it is evaluated for the ONE hit
+//     that wins (pass 2) from the stored end point of its march and arg-min child; the on-surface start classification
+//     (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) evaluates it where the reference does.  Lanes that need a normal
+//     wait until no lane of the wave is marching, then the dual-number code runs once for all of them — outside the march loop, and
+//     the march variables are re-initialised behind it, so nothing of a march is live across the normal code.
+//   * `lim`: a hit whose t exceeds the best t so far cannot win (System.jl:67), so an outside march stops once its running t0 exceeds
+//     it by the 1e-6 margin; t0 only grows by positive steps until the final sub-tolerance step (DESIGN.md "nearest-hit prune").
+//   * the miss cull (file header).  `calls` counts the reference's intersect3d calls, culled or not.
+// Returns the winning hit; its normal is in lane memory 0..2 (X.n is filled from there).
+template <bool ASPH, bool RETR = false>
+BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, int32_t hint_obj, int32_t hint_shape, uint32_t& calls, ChildCache& cc,
+                        const LaneMem& lm, bool probe = false, int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
+    enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2, FINAL = 3 };
+    double x_t = kinf();
+    int32_t x_shape = -1, x_obj = -1;
+    int32_t x_aux = 0;          // arg-min child of the best hit (SDF) or its face (mesh)
+    bool done = false;
+    int32_t skip_obj = -1;      // object already tested by the probe with this very ray (pure function => same `nothing`)
+    int32_t tested_shape = -1;  // shape tested in slot -1 (or by the probe) with this very ray
+    int32_t coat_obj = -1;      // plate splitter whose coating this ray has hit (its t: lane memory 6)
+    const int n_obj = S.n_objects, n_cand = S.n_cands;
+    lm.put3(3, pos_in);
+    BMO_NOUNROLL
+    for (int pass = RETR ? 0 : 1; pass <= 2; ++pass) {
+        bool in_pass;
+        int32_t hs = -1;  // shape tested in slot -1 of this pass (-1: none)
+        int o_lo = 0, o_hi = n_obj;
+        if (pass == 2) {
+            in_pass = x_shape >= 0;
+        } else if (RETR && pass == 0) {
+            in_pass = probe;
+            if (in_pass) {
+                calls += 1;
+                hs = hint_shape;
+                if (hint_shape >= 0) {
+                    o_hi = 0;
+                } else {
+                    o_lo = probe_obj;
+                    o_hi = probe_obj + 1;
                 }
             }
-            Hit res = no_hit();
-            BMO_NOUNROLL
-            for (int k = 0; k < np; ++k) {
-                const int32_t sid = k == 0 ? sh0 : (k == 1 ? sh1 : sh2);
-                const double lim = (o >= 0 && X.shape >= 0) ? X.t + 1e-6 * (1.0 + X.t) : kinf();
-                // the hinted shape was just tested with the same ray and returned `nothing` (else we had returned):
-                // intersect3d is a pure function of (shape, ray), so trace_all's repeat gives `nothing` again.
-                if (o >= 0 && sid == tested_shape) continue;
-#if defined(BMO_WATERFALL)
-                // one pass per distinct shape class (only the hinted slot can differ between lanes): see BMO_UNIFORM
-                Hit tmp = no_hit();
-                const int32_t cls = S.shapes[sid].flags >> BMO_SHAPE_CLASS_SHIFT;
-                for (bool pending = true; pending;) {
-                    const int32_t u = __builtin_amdgcn_readfirstlane(cls);
-                    if (u == cls) {
-                        tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim, cc);
-                        pending = false;
+        } else {
+            in_pass = !done;
+            if (RETR && probe) {
+                if (in_pass) {  // the probe missed
+                    if (probe_missed) *probe_missed = true;
+                    if (!fresh_allowed) {
+                        in_pass = false;
+                    } else {
+                        if (hint_shape < 0) skip_obj = probe_obj;
+                        calls += (uint32_t)n_obj;
                     }
                 }
-#else
-                Hit tmp = intersect_shape<ASPH>(S, sid, pos, dir, lim, cc);
-#endif
-                if (tmp.shape < 0) continue;
-                if (res.shape < 0) {
-                    res = tmp;
-                    continue;
-                }
-                if (kind == BMO_OBJ_PLATE_BS) {
-                    // res = coating, tmp = substrate: coating wins ties (isapprox) and when strictly nearer
-                    if (!(isapprox(res.t, tmp.t, 0.0) || res.t < tmp.t)) res = tmp;
-                } else if (tmp.t < res.t) {
-                    res = tmp;
-                }
+            } else if (in_pass) {
+                hs = hint_shape;
+                calls += hs >= 0 ? 1u : (uint32_t)n_obj;
             }
-            if (o < 0) {  // hinted shape
-                if (res.shape >= 0) {
-                    res.obj = hint_obj;
-                    X = res;
-                    done = true;
-                    break;
-                }
-                if (!fall_back) break;
-                calls += (uint32_t)S.n_objects;  // fall back to trace_all
-                continue;
-            }
-            if (res.shape < 0) continue;
-            res.obj = o;
-            if (X.shape < 0 || res.t < X.t) X = res;
         }
-        if (RETR && pass == 0 && X.shape >= 0) done = true;  // the stored path still holds
+        if (in_pass && hs >= 0) tested_shape = hs;
+        const int c_end = pass == 2 ? 0 : n_cand;
+        BMO_NOUNROLL
+        for (int c0 = 0; c0 == 0 || c0 < c_end; c0 += 64) {  // the candidate table in chunks of 64 (one mask); slot -1 belongs to the first
+            unsigned long long mask = 0;  // candidates of this chunk the lane has to march
+            const int c1 = c_end - c0 < 64 ? c_end - c0 : 64;
+            BMO_NOUNROLL
+            for (int q = c0 == 0 ? -1 : 0; q < c1; ++q) {  // wave-uniform; lanes skip the slots they do not use
+                const int slot = q < 0 ? -1 : c0 + q;
+                if (q == 0) {
+                    // ---- the candidates of this chunk the lane has to march: not culled by its bounding sphere, not excluded by the
+                    //      retrace probe's rules, not the shape tested a moment ago with the same ray
+                    const bool collect = in_pass && !done && o_lo < o_hi;
+                    if (BMO_WAVE_ANY(collect)) {
+                        const d3 p0 = lm.get3(3);
+                        BMO_NOUNROLL
+                        for (int i = 0; i < c1; ++i) {
+                            const BMO_KONST Cand& cd = S.cands[BMO_UNIFORM(c0 + i)];
+                            const int32_t co = BMO_UNIFORM(cd.obj), cs = BMO_UNIFORM(cd.sid);
+                            const bool want = collect && co >= o_lo && co < o_hi && co != skip_obj && cs != tested_shape &&
+                                              !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
+                            mask |= (unsigned long long)want << i;
+                        }
+                    }
+                }
+                bool take;
+                int32_t sid, info = 0, obj = -1;
+                if (slot < 0) {
+                    take = in_pass && (pass == 2 || hs >= 0);
+                    sid = pass == 2 ? x_shape : hs;
+                } else {
+                    take = ((mask >> q) & 1ull) != 0;
+                    if (!BMO_WAVE_ANY(take)) continue;
+                    const BMO_KONST Cand& cd = S.cands[BMO_UNIFORM(slot)];
+                    sid = BMO_UNIFORM(cd.sid);
+                    obj = BMO_UNIFORM(cd.obj);
+                    info = BMO_UNIFORM(cd.info);
+                }
+                // one pass per distinct shape among the lanes that take this slot (a candidate slot has one shape for all of them; the
+                // hinted shape and the winning shape can differ between lanes): inside, `sid` and everything read from its table entry
+                // is wave-uniform (scalar scene access, file header)
+                for (bool todo = take; todo;) {
+                    const int32_t usid = BMO_UNIFORM(sid);
+                    if (!bmo_same_id(usid, sid)) continue;
+                    todo = false;
+                    bool active = true;
+                    CShape& s = S.shapes[usid];
+                    const int32_t s_kind = s.kind, s_flags = s.flags;
+                    double lim = kinf();
+                    d3 pos{0, 0, 0};
+                    if (pass != 2) {
+                        pos = lm.get3(3);
+                        if (slot < 0) {
+                            if (cull_miss(s.bs_center[0], s.bs_center[1], s.bs_center[2], s.bs_radius, pos, dir0)) active = false;  // provable `nothing`
+                        } else if (x_shape >= 0) {  // (the mask holds only candidates whose sphere the ray's line meets)
+                            lim = x_t + 1e-6 * (1.0 + x_t);
+                            const double t_lb = cull_entry(s, pos, dir0);
+                            if (t_lb * (1.0 - 1e-9) - 1e-9 > lim) active = false;  // provable loser of the nearest-hit selection
+                        }
+                    }
+                    // a hit of this part at t (end point of the march p, arg-min child / face a): the reference's selection rules
+                    auto offer = [&](double t, int32_t a, const d3& p) {
+                        bool accept = x_shape < 0 || t < x_t;
+                        if (info & CAND_PLATE_COATING) {
+                            lm.m[6 * lm.stride] = t;
+                            coat_obj = obj;
+                        }
+                        if ((info & CAND_PLATE_SUBSTRATE) && coat_obj == obj) {
+                            // this plate's coating was hit by the same ray: it wins ties (isapprox) and when strictly nearer
+                            const double t_coat = lm.m[6 * lm.stride];
+                            if (isapprox(t_coat, t, 0.0) || t_coat < t) accept = false;
+                        }
+                        if (accept) {
+                            x_t = t;
+                            x_shape = usid;
+                            x_obj = slot < 0 ? hint_obj : obj;
+                            x_aux = a;
+                            lm.put3(0, p);
+                            if (slot < 0) done = true;
+                        }
+                    };
+                    if (s_kind == BMO_SHAPE_MESH) {
+                        if (pass == 2) {
+                            lm.put3(0, mesh_normal(S, s.tri_begin + x_aux));
+                        } else if (active) {
+                            int32_t fid = -1;
+                            const double t = mesh_nearest(S, s.tri_begin, s.tri_count, pos, dir0, fid);
+                            if (fid >= 0) offer(t, fid, d3{0, 0, 0});
+                        }
+                        active = false;
+                    }
+                    // ---- SDF shapes: sphere tracing
+                    if (BMO_WAVE_ANY(active)) {
+                        const ShapeHead H{s_kind, s.child_count, s_flags, s.child_begin, s.tri_begin};
+                        const bool exact = !(s_flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
+                        int phase = pass == 2 ? FINAL : CLASSIFY;
+                        bool pending = pass == 2;  // the lane waits for the normal site
+                        int32_t bc = 0;
+                        if (pass == 2) {
+                            pos = lm.get3(0);
+                            bc = x_aux;
+                        }
+                        BMO_NOUNROLL
+                        for (int round = 0; round < 2; ++round) {
+                            double dist = 0.0, t0 = 0.0, t_in = 0.0;
+                            int it = 1;  // iteration counter of the running march (inside, then outside)
+                            bool back = false;
+                            child_cache_reset(cc);
+                            // (a per-lane loop: lanes leave it as their marches end, the wave stays until the last one has left)
+                            while (active && !pending) {
+                                double moved = 0.0;  // how far this trip moves the evaluation point (Lipschitz memory of the union children)
+                                if (phase == INSIDE) {
+                                    pos = axpy3(pos, S.eps_ins, dir0);
+                                    t_in += S.eps_ins;
+                                    moved = S.eps_ins;
+                                } else if (phase == OUTSIDE) {
+                                    pos = axpy3(pos, back ? -dist : dist, dir0);
+                                    moved = fabs(dist);
+                                }
+                                const double d = sdf_any<ASPH>(S, H, s, pos, bc, cc, moved);
+                                if (phase == CLASSIFY) {
+                                    if (d > S.eps_srf) {
+                                        phase = OUTSIDE;
+                                        dist = d;
+                                        t0 = d;
+                                        it = 1;
+                                        if (!(it <= S.march_iters) || (exact && t0 > lim)) active = false;  // the reference returns `nothing`
+                                    } else {
+                                        pending = true;
+                                    }
+                                } else if (phase == INSIDE) {
+                                    if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
+                                        phase = OUTSIDE;
+                                        back = true;
+                                        dist = d;
+                                        t0 = d;
+                                        it = 1;
+                                        if (!(it <= S.march_iters)) active = false;
+                                    } else {
+                                        it += 1;
+                                        if (!(it <= S.march_iters)) active = false;
+                                    }
+                                } else {
+                                    dist = d;
+                                    t0 += d;
+                                    it += 1;
+                                    if (d < S.eps_ray) {
+                                        offer(back ? t_in - t0 : t0, bc, pos);
+                                        active = false;
+                                    } else {
+                                        // outside the bounding sphere and receding (the backward march runs along -dir: dot(co, -dir) =
+                                        // -dot(co, dir) exactly): provable miss, skip the rest of the 1000 evaluations
+                                        bool give_up = false;
+                                        const double R = s.bs_radius;
+                                        if (R >= 0.0) {
+                                            const d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
+                                            const double cd = dot3(co, dir0);
+                                            give_up = dot3(co, co) > R * R && (back ? cd < 0.0 : cd > 0.0);
+                                        }
+                                        if (give_up || (exact && !back && t0 > lim)  // provable loser of the nearest-hit selection
+                                            || !(it <= S.march_iters))
+                                            active = false;
+                                    }
+                                }
+                            }
+                            // nobody is marching: every lane still active waits for a normal (or nobody is left)
+                            if (!BMO_WAVE_ANY(active)) break;
+                            if (active) {
+                                // single normal site: the reference's normal3d, for the start classification on the surface
+                                // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the winning hit
+                                const d3 n = normal_at<ASPH>(S, usid, s_kind, H.child_begin, pos, bc);
+                                if (phase == FINAL) {
+                                    lm.put3(0, n);
+                                    active = false;
+                                } else if (dot3(dir0, n) <= 0) {  // entering
+                                    phase = INSIDE;
+                                    pending = false;
+                                    if (!(1 <= S.march_iters)) active = false;
+                                } else {
+                                    active = false;  // on the surface and leaving: no intersection
+                                }
+                            }
+                        }
+                    }
+                }
+                // trace_one missed the hinted shape: fall back to trace_all (System.jl:104-108); the retrace probe does not
+                if (slot < 0 && pass == 1 && take && !done) calls += (uint32_t)n_obj;
+            }
+        }
+        if (RETR && pass == 0 && x_shape >= 0) done = true;  // the stored path still holds
     }
+    Hit X;
+    X.t = x_t;
+    X.obj = x_obj;
+    X.shape = x_shape;
+    X.n = x_shape >= 0 ? lm.get3(0) : d3{0, 0, 0};
     return X;
 }
 
@@ -1505,8 +1632,8 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
 // is live across the three sphere-tracing marches.  On the GPU the backing store is the record itself (HBM / L2); held in
 // registers, the 3 rays + 3 hits were spilled around every march (1.5 KB of scratch per lane, 5 x the algorithmic HBM traffic).
 template <bool ASPH, bool RETR, class Rec>
-BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
-                           bool fresh_allowed = true, bool* probe_missed = nullptr) {
+BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
+                           int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     o.outcome = OUT_MISS;
     o.status = 0;
     o.hint_obj = o.hint_shape = -1;
@@ -1526,7 +1653,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         BMO_NOUNROLL
         for (int r = 0; r < 3; ++r) {
             const RayS ray = rec.ray(r);
-            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, probing, probe_obj, false, nullptr);
+            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, lm, probing, probe_obj, false, nullptr);
             rec.put_hit(r, X);
             if (r == 0) {
                 sh0 = X.shape;
@@ -1664,10 +1791,10 @@ struct GaussRecLocal {
     BMO_HD GaussIn load() const { return g; }
 };
 template <bool ASPH, bool RETR = false>
-BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, bool probe = false, int32_t probe_obj = -1,
-                       bool fresh_allowed = true, bool* probe_missed = nullptr) {
+BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
+                       int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}};
-    gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, probe, probe_obj, fresh_allowed, probe_missed);
+    gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed);
     o.Xc = rec.X[0];
     o.Xw = rec.X[1];
     o.Xd = rec.X[2];

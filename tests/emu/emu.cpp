@@ -78,6 +78,9 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
+    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)));
+    S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
+    S.cands = cands.data();
     S.eps_srf = d->eps_srf;
     S.eps_ray = d->eps_ray;
     S.eps_ins = d->eps_ins;
@@ -168,7 +171,9 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             } else {
                 double ccv[BMO_CC_MAX];
                 ChildCache cc{ccv, 1, 0};
-                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, probe, probe_obj, fresh_allowed, &missed);
+                double lmv[BMO_LANE_MEM];
+                const LaneMem lm{lmv, 1};
+                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
                 if (X.shape < 0) status = (old >= 0 && missed && !fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 else {
                     interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
@@ -353,6 +358,9 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
     S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
+    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)));
+    S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
+    S.cands = cands.data();
     S.eps_srf = d->eps_srf;
     S.eps_ray = d->eps_ray;
     S.eps_ins = d->eps_ins;
@@ -431,7 +439,9 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             else {
                 double ccv[BMO_CC_MAX];
                 ChildCache cc{ccv, 1, 0};
-                gauss_step<true, true>(S, r.g, r.o, c, cc, probe, probe_obj, fresh_allowed, &missed);
+                double lmv[BMO_LANE_MEM];
+                const LaneMem lm{lmv, 1};
+                gauss_step<true, true>(S, r.g, r.o, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
