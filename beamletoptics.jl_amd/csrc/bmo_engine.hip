@@ -365,29 +365,62 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
 #endif
     for (;;) {
         const Chunk C = b == 0 ? P.cur : P.inner[b - 1];
+        // ---- the tracing step.  Only what it needs is read before it, and nothing the interaction needs is computed before it: the
+        //      record addresses, node id and segment index are derived again behind it from a copy of the slot index the optimiser
+        //      cannot see through (`jj`), so no address or header value of this level is held in a register (or spilled) across the
+        //      marches — the ray's origin comes back from the lane memory of tracing_step, the hit's normal too.
+        RetraceLane rt;
+        int32_t x_obj = -1, x_shape = -1;
+        double x_t = kinf();
+        bool traced = false;  // the lane ran a tracing step at this level (its record is not a pushed-but-never-traced one)
+        const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
+        if (alive) {
+            const int64_t cap = C.cap;
+            const double* D = C.d;
+            const int32_t* I = C.i;
+            const int32_t flags = I[I_FLAGS * cap + j];
+            int32_t ho = I[I_HOBJ * cap + j], hs = I[I_HSHAPE * cap + j];
+            if (RETR) {
+                rt = retrace_lane(P, I[I_NODE * cap + j], I[I_K * cap + j]);
+                if (rt.old >= 0 && !rt.probe) ho = hs = -1;
+            }
+            traced = !((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed));  // else: pushed but never traced (System.jl:133)
+            if (traced) {
+                const d3 pos{D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]}, dir{D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+                // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
+                ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+#if defined(BMO_DEV_TIMELINE)
+                {
+                    const unsigned long long t = wall_clock64();
+                    tk0 += t - tk_last;
+                    tk_last = t;
+                }
+#endif
+                const Hit X = tracing_step<ASPH, RETR>(S, pos, dir, ho, hs, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+#if defined(BMO_DEV_TIMELINE)
+                {
+                    const unsigned long long t = wall_clock64();
+                    tk1 += t - tk_last;
+                    tk_last = t;
+                }
+#endif
+                x_t = X.t;
+                x_obj = X.obj;
+                x_shape = X.shape;
+            }
+        }
+        // ---- the interaction and the record of this level
+        int64_t jj = j;
+        asm volatile("" : "+v"(jj));
         bool survive = false, split = false, still = false, old_kids = false;
-        double opl_next = 0.0;
+        double opl_next = 0.0, lambda = 0.0;
+        int32_t node = -1, k = 0, li = 0;
         StepOut o;
         o.outcome = OUT_MISS;
         o.status = 0;
         o.hint_obj = o.hint_shape = -1;
         o.det_slot = -1;
-        RetraceLane rt;
-        int32_t node = -1, k = 0, li = 0, flags = 0, hobj = -1, hshape = -1;
-        RayS ray;
-        double opl_acc = 0.0, lambda = 0.0;
-        if (alive) {  // what the march needs; the rest of the record is read after it (fewer registers live across the march)
-            const int64_t cap = C.cap;
-            const double* D = C.d;
-            const int32_t* I = C.i;
-            node = I[I_NODE * cap + j];
-            k = I[I_K * cap + j];
-            flags = I[I_FLAGS * cap + j];
-            ray.pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
-            ray.dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
-            hobj = I[I_HOBJ * cap + j];
-            hshape = I[I_HSHAPE * cap + j];
-        }
+        o.det = nullptr;
         // header of the record that follows a surviving bounce: r_max flag and hint, with the retrace overrides
         auto next_header = [&](int32_t& fl, int32_t& ho, int32_t& hs) {
             fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
@@ -400,74 +433,52 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         };
         if (alive) {
             const int64_t cap = C.cap;
+            double* D = C.d;
+            int32_t* I = C.i;
+            node = I[I_NODE * cap + jj];
+            k = I[I_K * cap + jj];
             Hit X;
-            X.shape = -1;
-            X.obj = -1;
-            X.t = kinf();
+            X.t = x_t;
+            X.obj = x_obj;
+            X.shape = x_shape;
             X.n = {0, 0, 0};
             int status = 0;
-            o.det_slot = -1;
-            int32_t ho = hobj, hs = hshape;
-            if (RETR) {
-                rt = retrace_lane(P, node, k);
-                if (rt.old >= 0 && !rt.probe) ho = hs = -1;
-            }
-            if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
-                status = BMO_NODE_RMAX;  // pushed but never traced (System.jl:133)
+            if (!traced) {
+                status = BMO_NODE_RMAX;
+            } else if (x_shape < 0) {
+                status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
             } else {
-                // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
-                ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
-                const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
-#if defined(BMO_DEV_TIMELINE)
-                {
-                    const unsigned long long t = wall_clock64();
-                    tk0 += t - tk_last;
-                    tk_last = t;
-                }
-#endif
-                X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, ho, hs, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
-#if defined(BMO_DEV_TIMELINE)
-                {
-                    const unsigned long long t = wall_clock64();
-                    tk1 += t - tk_last;
-                    tk_last = t;
-                }
-#endif
-                if (X.shape < 0) {
-                    status = (RETR && rt.old >= 0 && rt.missed && !rt.fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
+                X.n = lm.get3(0);
+                RayS ray;  // the interaction's share of the record
+                ray.pos = lm.get3(3);
+                ray.dir = {D[3 * cap + jj], D[4 * cap + jj], D[5 * cap + jj]};
+                ray.n = D[6 * cap + jj];
+                if (KIND == BMO_BEAM_POLARIZED)
+                    for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + jj], D[(12 + 2 * c) * cap + jj]};
+                const double opl_acc = D[L::OPL * cap + jj];
+                li = P.nodes.li[node];
+                lambda = P.nodes.lambda[node];
+                o.det = P.nodes.hit + (int64_t)node * 9;  // a detector hit ends the beam: its record goes straight to the node's slot
+                interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
+                status = o.status;
+                if (o.outcome == OUT_CONTINUE) {
+                    survive = true;
+                    opl_next = opl_acc + X.t * ray.n;
+                } else if (o.outcome == OUT_SPLIT) {
+                    split = true;
+                    status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                    opl_next = opl_acc + X.t * ray.n;
                 } else {
-                    {   // the interaction's share of the record
-                        const double* D = C.d;
-                        ray.n = D[6 * cap + j];
-                        if (KIND == BMO_BEAM_POLARIZED)
-                            for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + j], D[(12 + 2 * c) * cap + j]};
-                        opl_acc = D[L::OPL * cap + j];
-                        li = P.nodes.li[node];
-                        lambda = P.nodes.lambda[node];
-                    }
-                    interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
-                    status = o.status;
-                    if (o.outcome == OUT_CONTINUE) {
-                        survive = true;
-                        opl_next = opl_acc + X.t * ray.n;
-                    } else if (o.outcome == OUT_SPLIT) {
-                        split = true;
-                        status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
-                        opl_next = opl_acc + X.t * ray.n;
-                    } else {
-                        status |= BMO_NODE_STOPPED;
-                    }
+                    status |= BMO_NODE_STOPPED;
                 }
             }
             // intersection part of this record
-            double* Dw = C.d;
-            int32_t* Iw = C.i;
-            Dw[7 * cap + j] = X.t;
-            Dw[8 * cap + j] = X.n.x;
-            Dw[9 * cap + j] = X.n.y;
-            Dw[10 * cap + j] = X.n.z;
-            Iw[I_OBJ * cap + j] = X.obj;
-            Iw[I_SHAPE * cap + j] = X.shape;
+            D[7 * cap + jj] = X.t;
+            D[8 * cap + jj] = X.n.x;
+            D[9 * cap + jj] = X.n.y;
+            D[10 * cap + jj] = X.n.z;
+            I[I_OBJ * cap + jj] = X.obj;
+            I[I_SHAPE * cap + jj] = X.shape;
             if (RETR) {
                 still = rt.old >= 0 && rt.probe && !rt.missed;  // the stored path held at this ray
                 old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
@@ -477,10 +488,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             if (!survive) {  // node ends here
                 P.nodes.nseg[node] = k + 1;
                 P.nodes.status[node] = status;
-                if (o.det_slot >= 0) {
-                    P.nodes.hit_det[node] = o.det_slot;
-                    for (int c = 0; c < 9; ++c) P.nodes.hit[(int64_t)node * 9 + c] = o.det[c];
-                }
+                if (o.det_slot >= 0) P.nodes.hit_det[node] = o.det_slot;
             }
         }
 #if defined(BMO_DEV_TIMELINE)
@@ -502,9 +510,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 if (alive && survive) {
                     int32_t fl, ho, hs;
                     next_header(fl, ho, hs);
-                    write_ray(N, j, o.next, node, k + 1, ho, hs, fl, opl_next);
+                    write_ray(N, jj, o.next, node, k + 1, ho, hs, fl, opl_next);
                 } else {
-                    N.i[I_NODE * N.cap + j] = -1;  // no record of this beam at this level
+                    N.i[I_NODE * N.cap + jj] = -1;  // no record of this beam at this level
                     alive = false;
                 }
             }

@@ -1177,7 +1177,7 @@ struct StepOut {
     RayS next;               // OUT_CONTINUE: new segment; OUT_SPLIT: transmitted child
     RayS refl;               // OUT_SPLIT: reflected child
     int det_slot;            // >= 0: a detector hit was produced
-    double det[9];
+    double* det;             // destination of the detector record, 9 doubles (the node's hit slot: written in place, set by the caller)
 };
 
 BMO_HD double n_medium(const SceneView& S, int medium, int li) { return S.n_table[medium * S.n_lambda + li]; }
@@ -1725,6 +1725,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         const double opl = r == 0 ? g.oplC : (r == 1 ? g.oplW : g.oplD);
         StepOut so;
         so.status = 0;
+        so.det = o.det + 9 * r;
         interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, entering_hint);
         o.status |= so.status;
         if (r == 0) {
@@ -1741,12 +1742,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         }
         if (so.det_slot >= 0) {
             o.det_slot = so.det_slot;
-            for (int c = 0; c < 9; ++c) {
-                if (r == 0) o.det[c] = so.det[c];
-                else if (r == 1) o.det[9 + c] = so.det[c];
-                else o.det[18 + c] = so.det[c];
-            }
-            o.n_det = r + 1;
+            o.n_det = r + 1;  // (the record went straight to o.det + 9 * r)
         }
         const int want = coating ? OUT_SPLIT : OUT_CONTINUE;
         if (so.outcome != want) all_continue = false;

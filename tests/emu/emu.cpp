@@ -141,6 +141,8 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             o.status = 0;
             o.hint_obj = o.hint_shape = -1;
             o.det_slot = -1;
+            double det9[9] = {0};
+            o.det = det9;
             uint32_t c = 0;
             int status = 0;
             bool survive = false;
@@ -194,7 +196,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                 nodes[r.node].status = status;
                 if (o.det_slot >= 0) {
                     nodes[r.node].hit_det = o.det_slot;
-                    std::memcpy(nodes[r.node].hit, o.det, sizeof o.det);
+                    std::memcpy(nodes[r.node].hit, det9, sizeof det9);
                 }
             }
             if (survive) {
