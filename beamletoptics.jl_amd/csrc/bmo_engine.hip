@@ -796,51 +796,83 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
 }
 
 // ------------------------------------------------------------------ small helper kernels
+// Coherence key of a root ray: the set of candidates (first 64 of the candidate table) whose bounding sphere the ray's line meets —
+// what the mask pre-pass of trace_all computes for the first bounce.  Rays with equal keys walk the same slots, so putting them next
+// to each other makes waves whose lanes agree on the shape they march (bmo_lane.hpp "scalar scene access": one waterfall pass).
+__global__ void root_key_kernel(const char* __restrict__ blob, BlobHeader hdr, const double* __restrict__ planes, int64_t n, unsigned long long* __restrict__ keys,
+                                int32_t* __restrict__ ids) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const SceneView S = view_of(blob, &hdr);
+    const d3 pos{planes[0 * n + j], planes[1 * n + j], planes[2 * n + j]}, dir{planes[3 * n + j], planes[4 * n + j], planes[5 * n + j]};
+    unsigned long long mask = 0;
+    const int nc = S.n_cands < 64 ? S.n_cands : 64;
+    for (int i = 0; i < nc; ++i) {
+        const BMO_KONST Cand& cd = S.cands[i];
+        mask |= (unsigned long long)!cull_miss(cd.cx, cd.cy, cd.cz, cd.R, pos, dir) << i;
+    }
+    keys[j] = mask;
+    ids[j] = (int32_t)j;
+}
+
+// Slot s of the first chunk holds root ray perm[s] (perm == nullptr: ray s); `slot_planes` are the batch's planes in slot order (the
+// batch itself when perm == nullptr, its binned copy otherwise), so every read and write here is coalesced.  Beam nodes keep the
+// bundle's numbering (root i is node i): everything downstream — result order, detector order, retrace — is independent of where a
+// ray sits in the chunk.  Thread i fills slot i of the chunk and node i of the node table.
 template <int KIND>
-__global__ void init_roots_kernel(const double* planes, const int32_t* lambda_idx, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max, int32_t n_planes) {
+__global__ void init_roots_kernel(const double* __restrict__ planes, const double* __restrict__ slot_planes, const int32_t* __restrict__ lambda_idx,
+                                  const int32_t* __restrict__ perm, int64_t n, Chunk c0, NodeArrays nodes, int32_t r_max, int32_t n_planes) {
     using L = Layout<KIND>;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int64_t cap = c0.cap;
-    double lam;
+    const double* Q = slot_planes;
+    const bool cont = KIND == BMO_BEAM_GAUSSIAN && n_planes >= BMO_PLANES_GAUSSIAN_CONTINUED;
     if (KIND == BMO_BEAM_GAUSSIAN) {
         for (int b = 0; b < 3; ++b) {
-            for (int p = 0; p < 6; ++p) c0.d[(11 * b + p) * cap + j] = planes[(6 * b + p) * n + j];
-            c0.d[(11 * b + 6) * cap + j] = planes[19 * n + j];
+            for (int p = 0; p < 6; ++p) c0.d[(11 * b + p) * cap + j] = Q[(6 * b + p) * n + j];
+            c0.d[(11 * b + 6) * cap + j] = Q[19 * n + j];
         }
         // accumulated lengths: zero for a fresh beamlet; a batch that continues solved beamlets brings them along (include/bmo.h)
-        const bool cont = n_planes >= BMO_PLANES_GAUSSIAN_CONTINUED;
-        c0.d[33 * cap + j] = cont ? planes[25 * n + j] : 0.0;  // lenA
-        c0.d[34 * cap + j] = cont ? planes[26 * n + j] : 0.0;  // lenB
-        c0.d[35 * cap + j] = cont ? planes[28 * n + j] : 0.0;  // oplC
-        c0.d[36 * cap + j] = cont ? planes[29 * n + j] : 0.0;  // oplW
-        c0.d[37 * cap + j] = cont ? planes[30 * n + j] : 0.0;  // oplD
-        lam = planes[18 * n + j];
-        nodes.aux[j * 4 + 0] = cont ? planes[27 * n + j] : 0.0;  // l0
-        nodes.aux[j * 4 + 1] = planes[20 * n + j];
-        nodes.aux[j * 4 + 2] = planes[21 * n + j];
-        nodes.aux[j * 4 + 3] = planes[22 * n + j];
+        c0.d[33 * cap + j] = cont ? Q[25 * n + j] : 0.0;  // lenA
+        c0.d[34 * cap + j] = cont ? Q[26 * n + j] : 0.0;  // lenB
+        c0.d[35 * cap + j] = cont ? Q[28 * n + j] : 0.0;  // oplC
+        c0.d[36 * cap + j] = cont ? Q[29 * n + j] : 0.0;  // oplW
+        c0.d[37 * cap + j] = cont ? Q[30 * n + j] : 0.0;  // oplD
     } else {
-        for (int p = 0; p < 6; ++p) c0.d[p * cap + j] = planes[p * n + j];
-        c0.d[6 * cap + j] = planes[7 * n + j];
+        for (int p = 0; p < 6; ++p) c0.d[p * cap + j] = Q[p * n + j];
+        c0.d[6 * cap + j] = Q[7 * n + j];
         if (KIND == BMO_BEAM_POLARIZED)
-            for (int p = 0; p < 6; ++p) c0.d[(11 + p) * cap + j] = planes[(8 + p) * n + j];
+            for (int p = 0; p < 6; ++p) c0.d[(11 + p) * cap + j] = Q[(8 + p) * n + j];
         c0.d[L::OPL * cap + j] = 0.0;
-        lam = planes[6 * n + j];
     }
-    c0.i[I_NODE * cap + j] = (int32_t)j;
+    c0.i[I_NODE * cap + j] = perm ? perm[j] : (int32_t)j;
     c0.i[I_K * cap + j] = 0;
     c0.i[I_HOBJ * cap + j] = -1;
     c0.i[I_HSHAPE * cap + j] = -1;
     c0.i[I_FLAGS * cap + j] = (1 < r_max) ? 0 : F_DEAD;
+    // node j = root ray j of the bundle
+    if (KIND == BMO_BEAM_GAUSSIAN) {
+        nodes.aux[j * 4 + 0] = cont ? planes[27 * n + j] : 0.0;  // l0
+        nodes.aux[j * 4 + 1] = planes[20 * n + j];
+        nodes.aux[j * 4 + 2] = planes[21 * n + j];
+        nodes.aux[j * 4 + 3] = planes[22 * n + j];
+    }
     nodes.root[j] = (int32_t)j;
     nodes.parent[j] = -1;
     nodes.nseg[j] = 1;
     nodes.status[j] = 0;
     nodes.li[j] = lambda_idx[j];
-    nodes.lambda[j] = lam;
+    nodes.lambda[j] = planes[(KIND == BMO_BEAM_GAUSSIAN ? 18 : 6) * n + j];
     nodes.hit_det[j] = -1;
     nodes.key[j] = 0;
+}
+// the batch's planes in slot order: out[p][s] = in[p][perm[s]]
+__global__ void bin_planes_kernel(const double* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int n_planes, double* __restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int64_t j = perm[s];
+    for (int p = 0; p < n_planes; ++p) out[(int64_t)p * n + s] = in[(int64_t)p * n + j];
 }
 
 // retrace tables of a finished solution
@@ -1235,6 +1267,8 @@ struct bmo_device_batch {
     int64_t n = 0;
     int n_planes = 0;
     DevBuf planes, li;
+    DevBuf perm;    // slot -> root ray, roots binned by coherence key (empty: bundle order is kept; root_key_kernel)
+    DevBuf binned;  // the planes in slot order (only with perm)
 };
 
 struct bmo_trace_result {
@@ -1510,7 +1544,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (n > 0) {
         // a retrace re-walks the stored first ray whatever r_max says (System.jl:197); root j re-walks old node j
         hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
-                           (const int32_t*)batch->li.p, n, cur, node_arrays(), prev ? 0x7fffffff : opts->r_max, (int32_t)batch->n_planes);
+                           (const double*)(batch->perm.p ? batch->binned.p : batch->planes.p), (const int32_t*)batch->li.p, (const int32_t*)batch->perm.p, n, cur,
+                           node_arrays(), prev ? 0x7fffffff : opts->r_max, (int32_t)batch->n_planes);
         if (prev) hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int32_t*)R->n_old.p, n);
     }
     lap("setup");
@@ -2104,6 +2139,35 @@ int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, 
     if (in->n) {
         HIP_TRY(hipMemcpy(b->planes.p, in->planes, (size_t)in->n * in->n_planes * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->li.p, in->lambda_idx, (size_t)in->n * 4, hipMemcpyHostToDevice));
+    }
+    // Roots are binned by coherence key once, here (a stable sort: bundle order within a key).  A bundle whose rays all have one key —
+    // a single disc source aimed at one train — keeps its order and costs nothing later; BMO_NO_BINNING=1 switches the step off.
+    if (in->n >= 4096 && scene->hdr.n_cands > 0 && !getenv("BMO_NO_BINNING")) {
+        const char* dblob = scene->device_blob(device, rc);
+        if (rc) return rc;
+        const int64_t n = in->n;
+        DevBuf keys, keys_out, ids, tmp;
+        if ((rc = keys.alloc((size_t)n * 8)) || (rc = keys_out.alloc((size_t)n * 8)) || (rc = ids.alloc((size_t)n * 4)) || (rc = b->perm.alloc((size_t)n * 4))) return rc;
+        hipLaunchKernelGGL(root_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dblob, scene->hdr, (const double*)b->planes.p, n,
+                           (unsigned long long*)keys.p, (int32_t*)ids.p);
+        const int bits = std::min(64, std::max(1, scene->hdr.n_cands));
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const unsigned long long*)keys.p, (unsigned long long*)keys_out.p, (const int32_t*)ids.p,
+                                                   (int32_t*)b->perm.p, (int)n, 0, bits, nullptr));
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, (const unsigned long long*)keys.p, (unsigned long long*)keys_out.p, (const int32_t*)ids.p,
+                                                   (int32_t*)b->perm.p, (int)n, 0, bits, nullptr));
+        unsigned long long k0 = 0, k1 = 0;
+        HIP_TRY(hipMemcpy(&k0, keys_out.p, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&k1, (const char*)keys_out.p + (size_t)(n - 1) * 8, 8, hipMemcpyDeviceToHost));
+        if (k0 == k1) {
+            b->perm.release();  // one key: nothing to bin
+        } else {
+            if ((rc = b->binned.alloc((size_t)n * in->n_planes * 8))) return rc;
+            hipLaunchKernelGGL(bin_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double*)b->planes.p, (const int32_t*)b->perm.p, n,
+                               (int)in->n_planes, (double*)b->binned.p);
+            HIP_TRY(hipDeviceSynchronize());  // the sort's temporaries go back to the pool
+        }
     }
     *out = b.release();
     return BMO_OK;

@@ -1017,8 +1017,11 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                     if (BMO_WAVE_ANY(active)) {
                         const ShapeHead H{s_kind, s.child_count, s_flags, s.child_begin, s.tri_begin};
                         const bool exact = !(s_flags & BMO_SHAPE_FLAG_INEXACT);  // the running-t prune needs a 1-Lipschitz SDF
-                        int phase = pass == 2 ? FINAL : CLASSIFY;
-                        bool pending = pass == 2;  // the lane waits for the normal site
+                        // the lane's march state in ONE integer (phase in bits 0-1): kept in a vector register and tested with vector
+                        // compares — as separate booleans, updated in different branches of a per-lane loop, it lived in scalar
+                        // lane masks that cost three scalar instructions per update and merge
+                        enum { ST_BACK = 4, ST_PENDING = 8, ST_ACTIVE = 16 };  // PENDING: the lane waits for the normal site
+                        int st = (active ? ST_ACTIVE : 0) | (pass == 2 ? (FINAL | ST_PENDING) : CLASSIFY);
                         int32_t bc = 0;
                         if (pass == 2) {
                             pos = lm.get3(0);
@@ -1028,80 +1031,73 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                         for (int round = 0; round < 2; ++round) {
                             double dist = 0.0, t0 = 0.0, t_in = 0.0;
                             int it = 1;  // iteration counter of the running march (inside, then outside)
-                            bool back = false;
                             child_cache_reset(cc);
                             // (a per-lane loop: lanes leave it as their marches end, the wave stays until the last one has left)
-                            while (active && !pending) {
+                            while ((st & (ST_ACTIVE | ST_PENDING)) == ST_ACTIVE) {
+                                const int phase = st & 3;
                                 double moved = 0.0;  // how far this trip moves the evaluation point (Lipschitz memory of the union children)
                                 if (phase == INSIDE) {
                                     pos = axpy3(pos, S.eps_ins, dir0);
                                     t_in += S.eps_ins;
                                     moved = S.eps_ins;
                                 } else if (phase == OUTSIDE) {
-                                    pos = axpy3(pos, back ? -dist : dist, dir0);
+                                    pos = axpy3(pos, (st & ST_BACK) ? -dist : dist, dir0);
                                     moved = fabs(dist);
                                 }
                                 const double d = sdf_any<ASPH>(S, H, s, pos, bc, cc, moved);
-                                if (phase == CLASSIFY) {
-                                    if (d > S.eps_srf) {
-                                        phase = OUTSIDE;
-                                        dist = d;
-                                        t0 = d;
-                                        it = 1;
-                                        if (!(it <= S.march_iters) || (exact && t0 > lim)) active = false;  // the reference returns `nothing`
-                                    } else {
-                                        pending = true;
-                                    }
-                                } else if (phase == INSIDE) {
-                                    if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
-                                        phase = OUTSIDE;
-                                        back = true;
-                                        dist = d;
-                                        t0 = d;
-                                        it = 1;
-                                        if (!(it <= S.march_iters)) active = false;
-                                    } else {
-                                        it += 1;
-                                        if (!(it <= S.march_iters)) active = false;
-                                    }
-                                } else {
+                                if (phase == OUTSIDE) {
                                     dist = d;
                                     t0 += d;
                                     it += 1;
                                     if (d < S.eps_ray) {
-                                        offer(back ? t_in - t0 : t0, bc, pos);
-                                        active = false;
+                                        offer((st & ST_BACK) ? t_in - t0 : t0, bc, pos);
+                                        st = 0;
                                     } else {
                                         // outside the bounding sphere and receding (the backward march runs along -dir: dot(co, -dir) =
                                         // -dot(co, dir) exactly): provable miss, skip the rest of the 1000 evaluations
-                                        bool give_up = false;
                                         const double R = s.bs_radius;
-                                        if (R >= 0.0) {
-                                            const d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
-                                            const double cd = dot3(co, dir0);
-                                            give_up = dot3(co, co) > R * R && (back ? cd < 0.0 : cd > 0.0);
-                                        }
-                                        if (give_up || (exact && !back && t0 > lim)  // provable loser of the nearest-hit selection
+                                        const d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
+                                        const double cd = dot3(co, dir0);
+                                        const bool recede = R >= 0.0 && dot3(co, co) > R * R && ((st & ST_BACK) ? cd < 0.0 : cd > 0.0);
+                                        if (recede || (exact && !(st & ST_BACK) && t0 > lim)  // provable loser of the nearest-hit selection
                                             || !(it <= S.march_iters))
-                                            active = false;
+                                            st = 0;
                                     }
+                                } else if (phase == CLASSIFY) {
+                                    if (d > S.eps_srf) {
+                                        st = ST_ACTIVE | OUTSIDE;
+                                        dist = d;
+                                        t0 = d;
+                                        it = 1;
+                                        if (!(it <= S.march_iters) || (exact && t0 > lim)) st = 0;  // the reference returns `nothing`
+                                    } else {
+                                        st |= ST_PENDING;
+                                    }
+                                } else {  // INSIDE
+                                    if (d > 0) {  // once outside, fall back to _raymarch_outside with -dir
+                                        st = ST_ACTIVE | ST_BACK | OUTSIDE;
+                                        dist = d;
+                                        t0 = d;
+                                        it = 1;
+                                    } else {
+                                        it += 1;
+                                    }
+                                    if (!(it <= S.march_iters)) st = 0;
                                 }
                             }
                             // nobody is marching: every lane still active waits for a normal (or nobody is left)
-                            if (!BMO_WAVE_ANY(active)) break;
-                            if (active) {
+                            if (!BMO_WAVE_ANY(st & ST_ACTIVE)) break;
+                            if (st & ST_ACTIVE) {
                                 // single normal site: the reference's normal3d, for the start classification on the surface
                                 // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the winning hit
                                 const d3 n = normal_at<ASPH>(S, usid, s_kind, H.child_begin, pos, bc);
-                                if (phase == FINAL) {
+                                if ((st & 3) == FINAL) {
                                     lm.put3(0, n);
-                                    active = false;
-                                } else if (dot3(dir0, n) <= 0) {  // entering
-                                    phase = INSIDE;
-                                    pending = false;
-                                    if (!(1 <= S.march_iters)) active = false;
+                                    st = 0;
+                                } else if (dot3(dir0, n) <= 0 && 1 <= S.march_iters) {  // entering
+                                    st = ST_ACTIVE | INSIDE;
                                 } else {
-                                    active = false;  // on the surface and leaving: no intersection
+                                    st = 0;  // on the surface and leaving: no intersection
                                 }
                             }
                         }
