@@ -516,14 +516,14 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
 // switch is inlined once; the three leaf values are folded as they come (one running value live, not three)
 template <class T, bool ASPH>
 BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
-    const int kind0 = BMO_UNIFORM(s.kind);
+    const int kind0 = s.kind;  // (read through a wave-uniform reference: a scalar already)
     const bool men = kind0 == BMO_SHAPE_MENISCUS;
     const int nleaf = men ? 3 : 1;
     T acc = T{};
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
         CShape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
-        const T v = sdf_leaf<T, ASPH>(leaf, men ? BMO_UNIFORM(leaf.kind) : kind0, men ? to_local(s, pt) : pt, S.coefs);
+        const T v = sdf_leaf<T, ASPH>(leaf, men ? leaf.kind : kind0, men ? to_local(s, pt) : pt, S.coefs);
         if (q == 0) acc = v;
         else if (q == 1) acc = jmin(acc, v);
         else acc = jmax(acc, -v);
@@ -567,14 +567,14 @@ BMO_HD void child_cache_reset(ChildCache& cc) {
 // The integer fields of a shape's table entry, read ONCE per intersect3d (every march iteration used to re-read them from LDS, one
 // dependent round trip each, because the compiler cannot hoist a load over the child-cache stores of the loop).
 struct ShapeHead {
-    int32_t kind, child_count, flags;  // wave-uniform (BMO_UNIFORM)
+    int32_t kind, child_count, flags;
     int32_t child_begin, tri_begin;    // per lane
 };
 BMO_HD ShapeHead shape_head(CShape& s) {
     ShapeHead h;
-    h.kind = BMO_UNIFORM(s.kind);
-    h.child_count = BMO_UNIFORM(s.child_count);
-    h.flags = BMO_UNIFORM(s.flags);
+    h.kind = s.kind;
+    h.child_count = s.child_count;
+    h.flags = s.flags;
     h.child_begin = s.child_begin;
     h.tri_begin = s.tri_begin;
     return h;
@@ -608,7 +608,7 @@ BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d
         bool skip = false;
         double lb = -kinf();
         // a union is flagged INEXACT when one of its children is (scene compiler): only then the child's own flag is looked up
-        const bool usable = uni && c < BMO_CC_MAX && (all_exact || !(BMO_UNIFORM(ch.flags) & BMO_SHAPE_FLAG_INEXACT));
+        const bool usable = uni && c < BMO_CC_MAX && (all_exact || !(ch.flags & BMO_SHAPE_FLAG_INEXACT));
         if (q > 0 && usable && cc.valid) {  // (the first child is always evaluated)
             const double bound = best > 0.0 ? best : 0.0;
             lb = cc.v[c * cc.stride] - acc;
@@ -939,8 +939,8 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                         const d3 p0 = lm.get3(3);
                         BMO_NOUNROLL
                         for (int i = 0; i < c1; ++i) {
-                            const BMO_KONST Cand& cd = S.cands[BMO_UNIFORM(c0 + i)];
-                            const int32_t co = BMO_UNIFORM(cd.obj), cs = BMO_UNIFORM(cd.sid);
+                            const BMO_KONST Cand& cd = S.cands[c0 + i];
+                            const int32_t co = cd.obj, cs = cd.sid;
                             const bool want = collect && co >= o_lo && co < o_hi && co != skip_obj && cs != tested_shape &&
                                               !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
                             mask |= (unsigned long long)want << i;
@@ -955,10 +955,10 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                 } else {
                     take = ((mask >> q) & 1ull) != 0;
                     if (!BMO_WAVE_ANY(take)) continue;
-                    const BMO_KONST Cand& cd = S.cands[BMO_UNIFORM(slot)];
-                    sid = BMO_UNIFORM(cd.sid);
-                    obj = BMO_UNIFORM(cd.obj);
-                    info = BMO_UNIFORM(cd.info);
+                    const BMO_KONST Cand& cd = S.cands[slot];
+                    sid = cd.sid;
+                    obj = cd.obj;
+                    info = cd.info;
                 }
                 // one pass per distinct shape among the lanes that take this slot (a candidate slot has one shape for all of them; the
                 // hinted shape and the winning shape can differ between lanes): inside, `sid` and everything read from its table entry

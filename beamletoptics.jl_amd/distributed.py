@@ -108,6 +108,92 @@ def all_gather_hit_lists(payloads, group=None):
     return out
 
 
+class HitExchange:
+    """The exchange step of a LOOP of solves without a host synchronisation per step.
+
+    all_gather_hit_lists learns the other ranks' hit counts with a small collective and a `.cpu()` before it can size the payload
+    buffers: one host round trip inside every step.  Here the counts travel IN the payload — row 0 of every rank's block holds its
+    per-detector counts — and the block size is the one the PREVIOUS step established (all ranks derived it from the same gathered
+    counts, so they agree on it without talking).  The gathered blocks are read on the host one step late, when the next solve has
+    been queued already.  A step whose hits do not fit the established block size (first step, or a workload that changed) falls
+    back to the synchronous exchange once and establishes the new size.
+
+        ex = HitExchange(widths)            # record width (columns) of every detector
+        p = ex.start(payloads)              # list of [count_d, width_d] float64 tensors of this rank, returns a pending object
+        ... queue the next solve ...
+        per_detector = p.wait()             # [(hits [total, width] in reference order, counts [world]) for every detector]
+    """
+
+    def __init__(self, widths, group=None):
+        self.widths, self.group = list(widths), group
+        self.world = dist.get_world_size(group)
+        self.rows = None  # established payload rows per rank block (without the header row)
+
+    def _pack(self, payloads, rows):
+        wmax = max(max(self.widths), len(self.widths))
+        dev = payloads[0].device
+        buf = torch.zeros((rows + 1, wmax), dtype=torch.float64, device=dev)
+        buf[0, : len(payloads)] = torch.tensor([p.shape[0] for p in payloads], dtype=torch.float64)  # header: this rank's counts (host ints)
+        at = 1
+        for p in payloads:
+            buf[at: at + p.shape[0], : p.shape[1]] = p
+            at += p.shape[0]
+        return buf
+
+    def start(self, payloads):
+        own = sum(int(p.shape[0]) for p in payloads)
+        if self.rows is None:
+            return self._sync(payloads)
+        fits = own <= self.rows
+        buf = self._pack(payloads if fits else [p[:0] for p in payloads], self.rows)
+        if not fits:
+            buf[0, : len(payloads)] = -1.0  # tells every rank (itself included) that this step has to be redone synchronously
+        if dist.get_backend(self.group) == "nccl":
+            flat = torch.empty((self.world * (self.rows + 1), buf.shape[1]), dtype=torch.float64, device=buf.device)
+            work = dist.all_gather_into_tensor(flat, buf, group=self.group, async_op=True)
+            outs = [flat[r * (self.rows + 1):(r + 1) * (self.rows + 1)] for r in range(self.world)]
+        else:
+            outs = [torch.empty_like(buf) for _ in range(self.world)]
+            work = dist.all_gather(outs, buf, group=self.group, async_op=True)
+        return _PendingExchange(self, work, outs, payloads)
+
+    def _sync(self, payloads):
+        pend = all_gather_hit_lists(payloads, self.group)
+        res = [p.wait() for p in pend]
+        tot = torch.stack([c for _, c in res]).sum(dim=0)  # rows per rank
+        self.rows = int(tot.max()) + int(tot.max()) // 64 + 16  # a little head-room: later steps of the same workload fit
+        return _DoneExchange(res)
+
+
+class _DoneExchange:
+    def __init__(self, res):
+        self.res = res
+
+    def wait(self):
+        return self.res
+
+
+class _PendingExchange:
+    def __init__(self, ex, work, outs, payloads):
+        self.ex, self.work, self.outs, self.payloads = ex, work, outs, payloads
+
+    def wait(self):
+        self.work.wait()
+        nd = len(self.payloads)
+        heads = torch.stack([o[0, :nd] for o in self.outs]).cpu()  # [world, n_det]: read one step late, the collective is long done
+        if bool((heads < 0).any()):  # some rank's hits did not fit: every rank sees it in the same gathered header and redoes the step
+            return self.ex._sync(self.payloads).wait()
+        counts = heads.to(torch.int64)
+        res = []
+        starts = torch.ones(len(self.outs), dtype=torch.int64)
+        for d in range(nd):
+            w = self.payloads[d].shape[1]
+            hits = torch.cat([self.outs[r][int(starts[r]): int(starts[r]) + int(counts[r, d]), :w] for r in range(len(self.outs))], dim=0)
+            res.append((hits, counts[:, d].contiguous()))
+            starts = starts + counts[:, d]
+        return res
+
+
 def all_reduce_field(field, group=None):
     """Sum of the per-rank Photodetector fields: every rank accumulates the field of ITS shard of beamlets with
     bmo_photodetector_field; the detector's field is their sum, one all-reduce of the nx x ny complex grid (viewed as float64

@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rays", type=int, default=0, help="root beams per GPU (0 = the BASELINE size of the workload)")
-    ap.add_argument("--workload", default="", help="c2 | c2v | c3 | c4 | c5 (default: c2 at N = 1, c5 at N > 1)")
+    ap.add_argument("--workload", default="", help="c2 | c2s | c2v | c3 | c4 | c5 (default: c2 at N = 1, c5 at N > 1)")
     ap.add_argument("--r-max", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=16384, help="rays for the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other configs and the PCIe-inclusive rates")
@@ -81,6 +81,10 @@ def workload(name, n, rank=0):
         return scenes.c2_scene()[0], scenes.c2_bundle(n, seed=SEED + rank), (
             f"BASELINE config 2: {lg} geometric Rays per GPU (0.3 mm object disc, 0.25 rad cone, seed {SEED} + rank) through the 10-element "
             "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors")
+    if name == "c2s":
+        return scenes.c2_scene()[0], scenes.c2_survey_bundle(n, seed=SEED + rank), (
+            f"config 2 scene, SURVEY 8(d)'s literal bundle: {lg} geometric Rays per GPU, Fibonacci disc of 0.8 x the first clear aperture (1.83 mm) at the object "
+            "plane, directions along the optical axis + a per-ray jitter of at most 2 mrad")
     if name == "c2v":
         return scenes.c2_scene()[0], scenes.c2_vignetted_bundle(n, seed=SEED + rank), (
             f"config 2 scene, vignetted bundle: {lg} geometric Rays per GPU, 2.0 mm object disc (0.87 x the first aperture) and 0.6 rad cone: 10 % of the rays miss the first lens, 45 % reach the splitter, the rest "
@@ -98,7 +102,7 @@ def workload(name, n, rank=0):
     raise SystemExit(f"unknown workload {name!r}")
 
 
-DEFAULT_RAYS = {"c2": 1 << 20, "c2v": 1 << 20, "c3": 1 << 20, "c4": 1 << 18, "c5": 1 << 21}
+DEFAULT_RAYS = {"c2": 1 << 20, "c2s": 1 << 20, "c2v": 1 << 20, "c3": 1 << 20, "c4": 1 << 18, "c5": 1 << 21}
 
 
 class Case:
@@ -150,6 +154,18 @@ class Case:
         return c["segments"] * BYTES_PER_BOUNCE[self.kind] + sum(n // sub * b for n, b in zip(c["det_counts"], self.det_bytes))
 
 
+def measured_traffic(name, n, r_max):
+    """HBM bytes per launch of the workload's step kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    this timed process): FETCH_SIZE x 2 + WRITE_SIZE, separate passes (MI355X_MICROARCH.md "HBM"), same command, default size only."""
+    tp = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if not os.path.exists(tp) or n != DEFAULT_RAYS.get(name) or r_max != 100:
+        return None, None
+    tj = json.load(open(tp)).get(name)
+    if not tj:
+        return None, None
+    return (2 * tj["fetch_size_bytes"] + tj["write_size_bytes"]) / tj["launches"], tj["source"]
+
+
 def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=None):
     alg = case.algorithmic_bytes(c)  # one solve on this rank
     achieved = alg * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -164,23 +180,66 @@ def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=N
     }
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(case, sample, r_max):
-    """Reference-algorithm CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
+    """Three CPU figures on bounded samples of the same workload, timed on this box's host cores (rank 0, N = 1 only):
+      [0] the oracle (op-for-op restatement of the reference algorithm, incl. its 1000-iteration misses) on ONE thread — the
+          reference's trace loop is serial (System.jl:463-468);                                      kind "port"
+      [1] the oracle, plain parallel-for over rays on every host core;                                   kind "port"
+      [2] the engine's own lane code compiled for the host (tests/emu: same culls, same shortcuts, same arithmetic as the HIP
+          kernels) on every host core — the "same algorithm on a CPU" figure that separates what the GPU buys from what the
+          result-preserving shortcuts buy.                                                             kind "port"
+    """
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+
     import numpy as np
+    import parity
     import pyoracle
 
-    threads = min(os.cpu_count() or 1, 32)
+    nproc = os.cpu_count() or 1
+    model = cpu_model()
     g = case.bundle
-    idx = (np.arange(sample) * (g.n // sample)).astype(np.int64)  # strided subsample of the benchmark bundle
-    b = case.bmo.RayBundle(g.kind, g.planes[:, idx])
+
+    def strided(k):
+        idx = (np.arange(k) * (g.n // k)).astype(np.int64)  # strided subsample of the benchmark bundle
+        return case.bmo.RayBundle(g.kind, g.planes[:, idx])
+
+    out = []
+    for threads, k in ((1, max(sample // 8, 64)), (nproc, sample)):
+        b = strided(min(k, g.n))
+        t = time.perf_counter()
+        ref = pyoracle.trace(case.scene, b, r_max, threads=threads)
+        dt = time.perf_counter() - t
+        out.append({"value": ref.n_intersect_calls / dt, "unit": "intersections/s", "cores": threads, "kind": "port",
+                    "what": "oracle: reference algorithm restated op for op (misses burn the reference's 1000 sdf evaluations)" + (
+                        ", one thread: the reference's trace loop is serial (System.jl:463-468)" if threads == 1 else ", plain parallel-for over rays on every host core"),
+                    "sample": f"every (N/{b.n})-th ray of the same bundle, same scene ({ref.n_intersect_calls} reference intersect3d calls, {dt:.1f} s wall)",
+                    "rays_per_s": b.n / dt, "nproc": nproc, "cpu": model})
+    # the lane code on the host: a sample 16 x larger (it skips what the engine skips), split over the cores
+    b = strided(min(sample * 16, g.n))
+    parts = max(nproc, 1)
+    cuts = [b.n * i // parts for i in range(parts + 1)]
+    subs = [case.bmo.RayBundle(b.kind, b.planes[:, cuts[i]:cuts[i + 1]]) for i in range(parts) if cuts[i + 1] > cuts[i]]
+    parity.emu_trace(case.scene, case.bmo.RayBundle(b.kind, b.planes[:, :8]), r_max)  # build / load the host library outside the timed region
     t = time.perf_counter()
-    ref = pyoracle.trace(case.scene, b, r_max, threads=threads)
+    with ThreadPoolExecutor(max_workers=parts) as ex:
+        calls = sum(r.n_intersect_calls for r in ex.map(lambda sb: parity.emu_trace(case.scene, sb, r_max), subs))
     dt = time.perf_counter() - t
-    return {"value": ref.n_intersect_calls / dt, "unit": "intersections/s", "cores": threads, "kind": "port",
-            "sample": f"every (N/{sample})-th ray of the same bundle, same scene ({ref.n_intersect_calls} reference intersect3d calls, {dt:.1f} s wall, "
-                      f"{threads} threads, plain parallel-for over rays)",
-            "rays_per_s": sample / dt}
+    out.append({"value": calls / dt, "unit": "intersections/s", "cores": nproc, "kind": "port",
+                "what": "the engine's lane code (csrc/bmo_lane.hpp: culls, prunes and child skips on) compiled for the host, one sub-bundle per core",
+                "sample": f"every (N/{b.n})-th ray of the same bundle, same scene ({calls} reference intersect3d calls counted, {dt:.1f} s wall)",
+                "rays_per_s": b.n / dt, "nproc": nproc, "cpu": model})
+    return out
 
 
 def pcie_rates(case, r_max, calls):
@@ -288,9 +347,10 @@ def main():
     case = Case(bmo, name, n_local, device_ord, rank)
     eng, n_det = case.eng, case.n_det
     in_flight = []  # exchange step of the previous trace, still travelling
+    exchange_state = bd.HitExchange(case.det_cols) if multi and n_det else None  # counts ride in the payload: no host round trip per step
 
     def finish_exchange():
-        out = [g.wait() for g in in_flight]  # (hits in reference order, counts) per detector
+        out = [g.wait() for g in in_flight]  # [(hits in reference order, counts) per detector] per pending exchange
         in_flight.clear()
         return out
 
@@ -308,7 +368,7 @@ def main():
                 eng.result_copy_hit_columns(res, s, case.det_cols[s], local.data_ptr(), cnt)
                 payloads.append(local if backend == "nccl" else local.cpu())
             if payloads:
-                in_flight.extend(bd.all_gather_hit_lists(payloads))
+                in_flight.append(exchange_state.start(payloads))
         return res, kms, nl
 
     def sync():
@@ -358,12 +418,7 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this timed
         # process): bytes per launch, measured with the same command at the default workload; null for any other workload.
-        traffic = traffic_src = None
-        tp = os.path.join(ROOT, "profiles", "r02_traffic_c2_1M.json")
-        if os.path.exists(tp) and name == "c2" and n_local == (1 << 20) and args.r_max == 100:
-            tj = json.load(open(tp))
-            traffic = (tj["fetch_bytes"] + tj["write_bytes"]) / tj["launches"]
-            traffic_src = tj["source"]
+        traffic, traffic_src = measured_traffic(name, n_local, args.r_max)
         unit_name = "beamlets_per_s" if case.kind == 2 else "rays_per_s"
         out = {
             "metric": "ray-surface intersections/s",
@@ -399,16 +454,17 @@ def main():
     if rank == 0 and not multi and not args.no_extras:
         # the other BASELINE configs at their per-GPU sizes, and the vignetted C2 bundle: 3 resident solves each after 1 warm-up
         cfgs = {}
-        for other in ("c2v", "c3", "c4", "c5"):
+        for other in ("c2s", "c2v", "c3", "c4", "c5"):
             if other == name:
                 continue
             oc = Case(bmo, other, DEFAULT_RAYS[other], device_ord)
             odt, okms, onl, c = oc.measure(args.r_max, 3, 1)
-            rl = roofline_of(oc, c, okms, onl, 3)
+            rl = roofline_of(oc, c, okms, onl, 3, *measured_traffic(other, DEFAULT_RAYS[other], args.r_max))
             cfgs[other] = {"workload": oc.text, "beams": oc.bundle.n, "ms": odt / 3 * 1e3, "kernel_ms": okms / 3, "launches": onl // 3,
                            "intersections_per_s": c["calls"] * 3 / odt, ("beamlets_per_s" if oc.kind == 2 else "rays_per_s"): oc.bundle.n * 3 / odt,
                            "segments": c["segments"], "beam_nodes": c["nodes"], "detector_hits": c["hits"],
-                           "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"]}
+                           "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"], "traffic": rl["traffic"], "traffic_unit": "bytes per launch",
+                           "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"]}
             oc.close()
         out["configs"] = cfgs
     if rank == 0:

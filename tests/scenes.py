@@ -119,6 +119,12 @@ def c2_bundle(n, lam=1.064e-6, seed=SEED):
     return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.3 * mm, lam=lam, e1=[1, 0, 0], cone=0.25, seed=seed)
 
 
+def c2_survey_bundle(n, lam=1.064e-6, seed=SEED):
+    """SURVEY.md §8(d)'s literal bundle for config 2: the Fibonacci disc of UniformDiscSource (BeamGroups.jl:232-243) with diameter
+    0.8 x the first clear aperture (2 x 1.144 mm), directions along the optical axis plus a per-ray angular jitter of at most 2 mrad."""
+    return disc_bundle(n, center=[0, 0, -0.77 * mm], direction=[0, 0, 1], diameter=0.8 * 2.288 * mm, lam=lam, e1=[1, 0, 0], jitter=2e-3, seed=seed)
+
+
 def c2_vignetted_bundle(n, lam=1.064e-6, seed=SEED, diameter=2.0 * mm, cone=0.6):
     """The ragged counterpart of c2_bundle: an object disc and a cone wider than the miniscope accepts, so part
     of the bundle misses the first aperture, is clipped at lens rims / mechanical rings or leaves the train between elements —

@@ -238,3 +238,53 @@ def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-gather" in line["config"]["parallelism"]
     assert line["config"]["name"] == "c5" and line["one_gpu_same_workload"]["value"] > 0
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    """HitExchange over a loop of steps: counts ride in the payload, block size from the previous step, one step that outgrows it."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmo_amd import distributed as bd
+
+    def payloads(step):  # two detectors (2 and 9 columns), ragged counts that depend on rank and step; step 3 outgrows the block
+        na = 3 + rank + (step % 2) + (200 if step == 3 and rank == 1 else 0)
+        nb = (0 if (rank + step) % 3 == 0 else 2 + step)
+        a = torch.arange(na * 2, dtype=torch.float64).reshape(-1, 2) + 1000 * rank + 10 * step
+        b = torch.arange(nb * 9, dtype=torch.float64).reshape(-1, 9) + 7000 * rank + 100 * step
+        return [a, b]
+
+    ex = bd.HitExchange([2, 9])
+    pending = None
+    for step in range(6):
+        mine = payloads(step)
+        nxt = ex.start(mine)
+        if pending is not None:
+            got, st = pending
+            # what every rank must see: the concatenation in rank order of what each rank sent at that step
+            sent = [_exchange_payloads(r, st) for r in range(world)]
+            for d, (hits, counts) in enumerate(got.wait()):
+                want = torch.cat([sent[r][d] for r in range(world)])
+                assert torch.equal(hits, want), (st, d)
+                assert counts.tolist() == [sent[r][d].shape[0] for r in range(world)]
+        pending = (nxt, step)
+    pending[0].wait()
+    assert ex.rows is not None and ex.rows >= 200  # step 3 re-established the block size
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _exchange_payloads(rank, step):
+    na = 3 + rank + (step % 2) + (200 if step == 3 and rank == 1 else 0)
+    nb = (0 if (rank + step) % 3 == 0 else 2 + step)
+    a = torch.arange(na * 2, dtype=torch.float64).reshape(-1, 2) + 1000 * rank + 10 * step
+    b = torch.arange(nb * 9, dtype=torch.float64).reshape(-1, 9) + 7000 * rank + 100 * step
+    return [a, b]
+
+
+def test_hit_exchange_without_per_step_sync(tmp_path):
+    mp.spawn(_exchange_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
