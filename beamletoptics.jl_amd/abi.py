@@ -142,8 +142,33 @@ class EngineMissing(RuntimeError):
     pass
 
 
+def _check_source_hash(lib):
+    """Refuse a library that was not built from the sources next to it (a stale, git-ignored .so pushed along with newer sources).
+    Skipped for an explicitly chosen build (BMO_ENGINE_LIB: A/B runs) and where the sources are not there to compare with."""
+    if os.environ.get("BMO_ENGINE_LIB"):
+        return
+    root = os.path.dirname(_HERE)
+    srcs = [os.path.join(_HERE, "csrc", "bmo_engine.hip"), os.path.join(_HERE, "csrc", "bmo_lane.hpp"), os.path.join(_HERE, "csrc", "bmo_readout.inc.hpp"),
+            os.path.join(root, "include", "bmo.h")]
+    if not all(os.path.exists(p) for p in srcs):
+        return
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in srcs:
+        h.update(open(p, "rb").read())
+    try:
+        lib.bmo_source_hash.restype = C.c_char_p
+        built = lib.bmo_source_hash().decode()
+    except AttributeError:
+        built = None
+    if built != h.hexdigest():
+        raise EngineMissing(f"{ENGINE_PATH} was not built from the sources in this tree (source hash {built!r} != {h.hexdigest()[:16]}...): "
+                            "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
+
+
 def load_engine():
-    """Load the HIP engine.  Fails loudly when the compiled library is missing."""
+    """Load the HIP engine.  Fails loudly when the compiled library is missing or stale."""
     global _engine
     if _engine is not None:
         return _engine
@@ -152,6 +177,7 @@ def load_engine():
             f"{ENGINE_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(ENGINE_PATH)
+    _check_source_hash(lib)
     vp = C.c_void_p
     lib.bmo_version.restype = C.c_int
     lib.bmo_last_error.restype = C.c_char_p

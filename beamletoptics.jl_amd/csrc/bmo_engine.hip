@@ -326,7 +326,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     const int64_t m = P.cur.count;
     const bool valid = j < m;
 #if defined(BMO_DEV_TIMELINE)
-    if (P.tl && (threadIdx.x & 63) == 0) P.tl[2 * (j >> 6)] = wall_clock64();
+    if (P.tl && (threadIdx.x & 63) == 0 && (j & ~(int64_t)63) < P.cur.count) P.tl[2 * (j >> 6)] = wall_clock64();
 #endif
 
     // A lane carries nothing but `alive` from one fused bounce to the next: it writes its next record and reads it back at the
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         //      never read (Chunk::wl) —, then compact into the next launch's chunk
         if (P.wave_last && lane_id() == 0) P.wave_last[j >> 6] = (uint8_t)b;
 #if defined(BMO_DEV_TIMELINE)
-        if (P.tl && (threadIdx.x & 63) == 0) {
+        if (P.tl && (threadIdx.x & 63) == 0 && (j & ~(int64_t)63) < P.cur.count) {  // (tail waves of the grid have no slot in the timeline)
             P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
             const int64_t nw = (P.cur.count + 63) / 64;
             atomicAdd(&P.tl[2 * nw + 0], tk0);
@@ -1142,6 +1142,33 @@ void pool_release_all() {
     g_pool_bytes = 0;
 }
 
+// Deferred release (run_trace): device and pinned blocks released on this thread while a PoolHold lives are parked in it and go
+// back to the pools when it dies, after the stream has been synchronised.  PoolHold::Now lifts the deferral inside a scope whose
+// releases are known to be safe at once (a chunk whose launch has completed, record_segments = 0).
+struct PoolHold;
+thread_local PoolHold* g_hold = nullptr;
+void host_pool_give(void* p, size_t bytes);
+struct PoolHold {
+    hipStream_t stream;
+    std::vector<PoolBlock> dev;
+    std::vector<std::pair<void*, size_t>> host;
+    PoolHold* prev;
+    explicit PoolHold(hipStream_t s) : stream(s), prev(g_hold) { g_hold = this; }
+    ~PoolHold() {
+        g_hold = prev;
+        (void)hipStreamSynchronize(stream);
+        for (auto& b : dev) pool_give(b.p, b.bytes, b.device);
+        for (auto& h : host) host_pool_give(h.first, h.second);
+    }
+    PoolHold(const PoolHold&) = delete;
+    PoolHold& operator=(const PoolHold&) = delete;
+    struct Now {
+        PoolHold* saved;
+        Now() : saved(g_hold) { g_hold = nullptr; }
+        ~Now() { g_hold = saved; }
+    };
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -1169,7 +1196,10 @@ struct DevBuf {
         return BMO_OK;
     }
     void release() {
-        if (p) pool_give(p, bytes, device);
+        if (p) {
+            if (g_hold) g_hold->dev.push_back({p, bytes, device});
+            else pool_give(p, bytes, device);
+        }
         p = nullptr;
         bytes = 0;
     }
@@ -1186,6 +1216,17 @@ constexpr size_t HOST_POOL_CAP = (size_t)16 << 30;
 std::mutex g_hpool_mu;
 std::vector<PoolBlock> g_hpool;
 size_t g_hpool_bytes = 0;
+
+void host_pool_give(void* p, size_t bytes) {
+    std::unique_lock<std::mutex> lk(g_hpool_mu);
+    if (g_hpool_bytes + bytes <= HOST_POOL_CAP) {
+        g_hpool.push_back({p, bytes, 0});
+        g_hpool_bytes += bytes;
+    } else {
+        lk.unlock();
+        (void)hipHostFree(p);
+    }
+}
 
 struct HostBuf {
     void* p = nullptr;
@@ -1218,14 +1259,8 @@ struct HostBuf {
     }
     void release() {
         if (!p) return;
-        std::unique_lock<std::mutex> lk(g_hpool_mu);
-        if (g_hpool_bytes + bytes <= HOST_POOL_CAP) {
-            g_hpool.push_back({p, bytes, 0});
-            g_hpool_bytes += bytes;
-        } else {
-            lk.unlock();
-            (void)hipHostFree(p);
-        }
+        if (g_hold) g_hold->host.emplace_back(p, bytes);
+        else host_pool_give(p, bytes);
         p = nullptr;
         bytes = 0;
     }
@@ -1405,6 +1440,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     hipStream_t stream = ctx.stream;
     hipEvent_t ev_t0 = ctx.ev[2], ev_t1 = ctx.ev[3];
     HIP_TRY(hipEventRecord(ev_t0, stream));
+    // Every exit path — the error returns too — waits for what has been queued BEFORE the temporaries of this function go back to the
+    // shared pools: a kernel or copy still in flight must not write into a block another host thread has been handed.
+    // While `hold` lives, blocks released on this thread are parked in it; its destructor (it is declared before every temporary, so it
+    // runs after theirs) synchronises the stream and only then hands them to the pools.
+    PoolHold hold(stream);
 
     const int nsub = KIND == BMO_BEAM_GAUSSIAN ? 3 : 1;
     // node arrays: roots + room for children (grown on demand)
@@ -1457,6 +1497,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             (void)hipStreamSynchronize(stream);
             std::swap(b.p, nb.p);
             std::swap(b.bytes, nb.bytes);
+            PoolHold::Now at_once;  // the old table goes back right away (the copy above has completed)
+            nb.release();
             return BMO_OK;
         };
         int r;
@@ -1507,7 +1549,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         top += need;
         return BMO_OK;
     };
-    auto drop_chunk = [&](const Chunk& c) {  // record_segments = 0 only
+    auto drop_chunk = [&](const Chunk& c) {  // record_segments = 0 only; called behind the synchronisation of the chunk's launch
+        PoolHold::Now at_once;
         for (size_t q = 0; q < R->arena.size(); ++q)
             if (R->arena[q]->p == (void*)c.d) {
                 R->arena.erase(R->arena.begin() + (long)q);
@@ -1606,7 +1649,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         uint8_t* wl = nullptr;
         if (keep_log && n_fuse > 1) {
             auto b = std::make_unique<DevBuf>();
-            if ((rc = b->alloc((size_t)((m + 63) / 64)))) return rc;
+            // one byte per wave of the GRID, not of the batch: the tail waves of the last workgroup (no record, j >= m) note their level too
+            if ((rc = b->alloc((size_t)((m + BMO_BLOCK - 1) / BMO_BLOCK) * (BMO_BLOCK / 64)))) return rc;
             wl = static_cast<uint8_t*>(b->p);
             R->wave_last.push_back(std::move(b));
         }
@@ -1618,7 +1662,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
                 inner[q] = inner[0];  // nobody reads the log: a lane's in-place record is dead once it has been read back, one chunk serves all levels
                 continue;
             }
-            if ((rc = new_chunk(m, inner[q]))) return rc;
+            if ((rc = new_chunk(m, inner[q]))) {
+                if (rc != BMO_ERR_OOM || q == 0) return rc;
+                n_fuse = q + 1;  // no room for this many in-place levels: fuse the ones that fit (the launch before fused fewer, too)
+                rc = BMO_OK;
+                break;
+            }
             inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
             inner[q].wl = wl;
             inner[q].level = q + 1;
@@ -1704,6 +1753,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             // the levels behind them were never touched: their room goes back to the arena (allocation is a bump, so everything
             // allocated after the last level in use belongs to them)
             if (used + 1 < n_fuse) {
+                PoolHold::Now at_once;  // (the launch has completed: nothing in flight touches these blocks)
                 while (R->arena.size() > blocks_after[used]) R->arena.pop_back();
                 top = top_after[used];
             }
@@ -1971,6 +2021,14 @@ int dl(std::vector<T>& h, const void* d, size_t count) {
 extern "C" {
 
 int bmo_version(void) { return BMO_ABI_VERSION; }
+#if !defined(BMO_SOURCE_HASH)
+#define BMO_SOURCE_HASH ""
+#endif
+// (the marker in front lets the build script read the hash out of the file without loading the library)
+const char* bmo_source_hash(void) {
+    static const char tagged[] = "BMO_SOURCE_HASH=" BMO_SOURCE_HASH;
+    return tagged + 16;
+}
 const char* bmo_last_error(void) { return g_err.c_str(); }
 
 int bmo_device_count(void) {

@@ -207,6 +207,7 @@ def cpu_baseline(case, sample, r_max):
     import pyoracle
 
     nproc = os.cpu_count() or 1
+    workers = min(nproc, 32)  # a GPU box shares its host: 32 threads were the fastest the oracle ran with (round 2), more only contend
     model = cpu_model()
     g = case.bundle
 
@@ -215,19 +216,19 @@ def cpu_baseline(case, sample, r_max):
         return case.bmo.RayBundle(g.kind, g.planes[:, idx])
 
     out = []
-    for threads, k in ((1, max(sample // 8, 64)), (nproc, sample)):
+    for threads, k in ((1, max(sample // 8, 64)), (workers, sample)):
         b = strided(min(k, g.n))
         t = time.perf_counter()
         ref = pyoracle.trace(case.scene, b, r_max, threads=threads)
         dt = time.perf_counter() - t
         out.append({"value": ref.n_intersect_calls / dt, "unit": "intersections/s", "cores": threads, "kind": "port",
                     "what": "oracle: reference algorithm restated op for op (misses burn the reference's 1000 sdf evaluations)" + (
-                        ", one thread: the reference's trace loop is serial (System.jl:463-468)" if threads == 1 else ", plain parallel-for over rays on every host core"),
+                        ", one thread: the reference's trace loop is serial (System.jl:463-468)" if threads == 1 else f", plain parallel-for over rays on {workers} threads"),
                     "sample": f"every (N/{b.n})-th ray of the same bundle, same scene ({ref.n_intersect_calls} reference intersect3d calls, {dt:.1f} s wall)",
                     "rays_per_s": b.n / dt, "nproc": nproc, "cpu": model})
     # the lane code on the host: a sample 16 x larger (it skips what the engine skips), split over the cores
     b = strided(min(sample * 16, g.n))
-    parts = max(nproc, 1)
+    parts = max(workers, 1)
     cuts = [b.n * i // parts for i in range(parts + 1)]
     subs = [case.bmo.RayBundle(b.kind, b.planes[:, cuts[i]:cuts[i + 1]]) for i in range(parts) if cuts[i + 1] > cuts[i]]
     parity.emu_trace(case.scene, case.bmo.RayBundle(b.kind, b.planes[:, :8]), r_max)  # build / load the host library outside the timed region
@@ -235,7 +236,7 @@ def cpu_baseline(case, sample, r_max):
     with ThreadPoolExecutor(max_workers=parts) as ex:
         calls = sum(r.n_intersect_calls for r in ex.map(lambda sb: parity.emu_trace(case.scene, sb, r_max), subs))
     dt = time.perf_counter() - t
-    out.append({"value": calls / dt, "unit": "intersections/s", "cores": nproc, "kind": "port",
+    out.append({"value": calls / dt, "unit": "intersections/s", "cores": workers, "kind": "port",
                 "what": "the engine's lane code (csrc/bmo_lane.hpp: culls, prunes and child skips on) compiled for the host, one sub-bundle per core",
                 "sample": f"every (N/{b.n})-th ray of the same bundle, same scene ({calls} reference intersect3d calls counted, {dt:.1f} s wall)",
                 "rays_per_s": b.n / dt, "nproc": nproc, "cpu": model})

@@ -276,6 +276,10 @@ typedef struct bmo_trace_result bmo_trace_result; /* opaque */
 /* ---------------------------------------------------------------- functions */
 int bmo_version(void);
 const char* bmo_last_error(void);
+/* SHA-256 (hex) of the engine sources this library was built from (csrc/bmo_engine.hip, bmo_lane.hpp, bmo_readout.inc.hpp and this
+   header, in that order), recorded by the build; "" for a build that did not record one.  The host side compares it with the sources
+   it finds next to the library and refuses a stale binary (there is no reference counterpart: housekeeping of the boundary). */
+const char* bmo_source_hash(void);
 
 /* Number of usable HIP devices (0 = none). */
 int bmo_device_count(void);

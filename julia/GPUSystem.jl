@@ -595,7 +595,12 @@ function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Boo
                 ccall((:bmo_scene_destroy, LIBBMO), Cint, (Ptr{Cvoid},), scene[])
             end
         end
-        check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+        try
+            check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+        catch
+            ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])   # the solution stays in HBM otherwise (ADVICE r02)
+            rethrow()
+        end
         hv = HostView(view[])
         if any(s -> s & NODE_RETRACE_STALE != 0, hv.status)
             # the one place the engine deviates from retrace_system! (DESIGN.md §6 f1): let the reference handle this solve
@@ -606,9 +611,12 @@ function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Boo
             raise_status(hv)
             rebuild_beams!(roots, kind, hv, leaves, tb.shape_refs)
             push_detector_data!(tb, hv, res[])
-        catch
+        catch e
             ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
             forget!(sys, key)
+            # beams (and possibly some detectors) have been updated already: falling back to the wrapped System now would append the
+            # detector data a second time, so an "unsupported" raised this late is an error, not a fallback (ADVICE r02)
+            e isa BmoUnsupported && error("GPUSystem: " * sprint(showerror, e) * " (raised after the beams were rebuilt; no CPU fallback at this point)")
             rethrow()
         end
         forget!(sys, key)

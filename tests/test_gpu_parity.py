@@ -54,6 +54,16 @@ def test_c2_bit_exact(engine_ok, oracle):
     assert got.det_count.sum() > 0
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 191, 257, 321, 4096 + 129])
+def test_ragged_batch_sizes_read_the_segment_log(engine_ok, oracle, n):
+    """Batch sizes that are not a multiple of the workgroup (m % 256 in 1..192): the tail waves of the grid have no record
+    but still pass the fused level loop and note how far they got (Chunk::wl); the segment log of every beam must come out whole."""
+    system, _ = c2_scene()
+    got, ref = run_both(oracle, system, c2_bundle(n))
+    compare(got, ref, 0.0, f"c2 n={n}")
+    assert got.n_records == int(ref.node_nseg.sum())
+
+
 @pytest.mark.parametrize("r_max", [-3, 0, 1, 2, 3, 10])
 def test_r_max_cap(engine_ok, oracle, r_max):
     system, _ = c2_scene()
