@@ -926,35 +926,20 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
         const int c_end = pass == 2 ? 0 : n_cand;
         BMO_NOUNROLL
         for (int c0 = 0; c0 == 0 || c0 < c_end; c0 += 64) {  // the candidate table in chunks of 64 (one mask); slot -1 belongs to the first
-            unsigned long long mask = 0;  // candidates of this chunk the lane has to march
+            unsigned long long mask = 0;       // candidates of this chunk the lane has to march
+            unsigned long long wave_mask = 0;  // ... some lane of the wave has to march (a scalar: the slot loop walks its set bits)
             const int c1 = c_end - c0 < 64 ? c_end - c0 : 64;
+            // slot -1 (first chunk only), then the set bits of wave_mask in rising order; q == -2: a later chunk starts with the collection
             BMO_NOUNROLL
-            for (int q = c0 == 0 ? -1 : 0; q < c1; ++q) {  // wave-uniform; lanes skip the slots they do not use
+            for (int q = c0 == 0 ? -1 : -2;;) {  // wave-uniform; lanes skip the slots they do not use
                 const int slot = q < 0 ? -1 : c0 + q;
-                if (q == 0) {
-                    // ---- the candidates of this chunk the lane has to march: not culled by its bounding sphere, not excluded by the
-                    //      retrace probe's rules, not the shape tested a moment ago with the same ray
-                    const bool collect = in_pass && !done && o_lo < o_hi;
-                    if (BMO_WAVE_ANY(collect)) {
-                        const d3 p0 = lm.get3(3);
-                        BMO_NOUNROLL
-                        for (int i = 0; i < c1; ++i) {
-                            const BMO_KONST Cand& cd = S.cands[c0 + i];
-                            const int32_t co = cd.obj, cs = cd.sid;
-                            const bool want = collect && co >= o_lo && co < o_hi && co != skip_obj && cs != tested_shape &&
-                                              !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
-                            mask |= (unsigned long long)want << i;
-                        }
-                    }
-                }
-                bool take;
-                int32_t sid, info = 0, obj = -1;
-                if (slot < 0) {
+                bool take = false;
+                int32_t sid = 0, info = 0, obj = -1;
+                if (q == -1) {
                     take = in_pass && (pass == 2 || hs >= 0);
                     sid = pass == 2 ? x_shape : hs;
-                } else {
+                } else if (q >= 0) {
                     take = ((mask >> q) & 1ull) != 0;
-                    if (!BMO_WAVE_ANY(take)) continue;
                     const BMO_KONST Cand& cd = S.cands[slot];
                     sid = cd.sid;
                     obj = cd.obj;
@@ -1105,6 +1090,36 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                 }
                 // trace_one missed the hinted shape: fall back to trace_all (System.jl:104-108); the retrace probe does not
                 if (slot < 0 && pass == 1 && take && !done) calls += (uint32_t)n_obj;
+                // ---- next slot: the lowest candidate of this chunk that some lane still has to march
+                if (q < 0) {
+                    if (pass == 2) break;
+                    // the candidates of this chunk the lane has to march: not culled by its bounding sphere, not excluded by the retrace
+                    // probe's rules, not the shape tested a moment ago with the same ray.  Four table entries per trip so that their
+                    // scalar loads are in flight together.
+                    const bool collect = in_pass && !done && o_lo < o_hi;
+                    if (c1 > 0 && BMO_WAVE_ANY(collect)) {
+                        const d3 p0 = lm.get3(3);
+                        BMO_NOUNROLL
+                        for (int i0 = 0; i0 < c1; i0 += 4) {
+                            bool want[4];
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = i0 + u < c1 ? i0 + u : c1 - 1;
+                                const BMO_KONST Cand& cd = S.cands[c0 + i];
+                                const int32_t co = cd.obj, cs = cd.sid;
+                                want[u] = i0 + u < c1 && collect && co >= o_lo && co < o_hi && co != skip_obj && cs != tested_shape &&
+                                          !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
+                            }
+                            for (int u = 0; u < 4; ++u) {
+                                mask |= (unsigned long long)want[u] << (i0 + u);
+                                if (BMO_WAVE_ANY(want[u])) wave_mask |= 1ull << (i0 + u);
+                            }
+                        }
+                    }
+                } else {
+                    wave_mask &= ~(1ull << q);
+                }
+                if (!wave_mask) break;
+                q = (int)__builtin_ctzll(wave_mask);
             }
         }
         if (RETR && pass == 0 && x_shape >= 0) done = true;  // the stored path still holds
