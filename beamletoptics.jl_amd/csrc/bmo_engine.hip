@@ -75,7 +75,7 @@ struct BlobHeader {
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
     uint32_t has_asphere, off_cands;
-    int32_t n_cands, pad[3];
+    int32_t n_cands, has_meniscus, pad[2];
 };
 
 // `h`: the blob's header; the kernels read it from their arguments (scalar loads the compiler may repeat instead of holding the
@@ -289,34 +289,17 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
 #define BMO_MIN_WAVES 3  /* <= 168 VGPRs.  Round 3: with the scene tables read by scalar loads tracing_step is spill-free at 168 registers and 3 waves/SIMD
                             beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5 (profiles/r03_ab_scalar_scene.txt); 4 (128) still spills in the march */
 #endif
-// Scene access: the LDS variant derives every table pointer from the __shared__ array so the compiler emits
-// ds_read (a run-time select between an LDS and a global pointer degrades ALL table reads to flat_load: measured
-// 510 flat loads per wave and VALU active only 17 % of wave residency).  The non-LDS variant (scene > 120 KB) reads
-// the blob from global memory / L2.
-template <bool LDS>
-__device__ __forceinline__ SceneView stage_scene(const StepParams& P, char* lds) {
-    if constexpr (LDS) {
-        const uint4* src = reinterpret_cast<const uint4*>(P.blob);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (uint32_t q = threadIdx.x; q < P.blob_bytes / 16; q += blockDim.x) dst[q] = src[q];
-        __syncthreads();
-        return view_of((const char*)lds, &P.hdr);
-    } else {
-        return view_of((const char*)P.blob, &P.hdr);
-    }
-}
-
 // One launch advances every active beam by up to P.n_fuse bounces.  Bounce 0 reads its records from P.cur; a lane that goes
 // on writes its next record IN PLACE (same slot j) into P.inner[b] and traces it in the same launch — no compaction, no host
 // round trip, the ray stays in registers; lanes that ended leave an invalid record (node = -1) in the inner chunks.  The fused
 // loop ends for a WAVE when one of its lanes splits (children need the slot allocation below) or when none goes on; the four waves
 // of a workgroup run their loops independently and meet at the block-wide allocation.  Survivors of the last fused bounce and
 // beam-splitter children are compacted into P.nxt as before.
-template <int KIND, bool LDS, bool ASPH, bool RETR>
+template <int KIND, int EXT, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    SceneView S = stage_scene<LDS>(P, lds);
-    char* scratch = lds + (LDS ? P.blob_bytes : 0u);
+    const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
+    char* scratch = lds;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr->next_count[P.parity ^ 1] = 0;
         P.ctr->max_level[P.parity ^ 1] = 0;
@@ -396,7 +379,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     tk_last = t;
                 }
 #endif
-                const Hit X = tracing_step<ASPH, RETR>(S, pos, dir, ho, hs, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                const Hit X = tracing_step<EXT, RETR>(S, pos, dir, ho, hs, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
 #if defined(BMO_DEV_TIMELINE)
                 {
                     const unsigned long long t = wall_clock64();
@@ -645,11 +628,11 @@ struct GaussRecDevNoHint : GaussRecDev {
     __device__ int32_t hint_shape() const { return -1; }
 };
 
-template <bool LDS, bool ASPH, bool RETR>
+template <int EXT, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    SceneView S = stage_scene<LDS>(P, lds);
-    char* scratch = lds + (LDS ? P.blob_bytes : 0u);
+    const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
+    char* scratch = lds;
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = P.cur.count, cap = P.cur.cap;
@@ -685,9 +668,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
             if (RETR && no_hint) {
                 GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node}};
-                gauss_step_rec<ASPH, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             } else {
-                gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             }
             status = o.status;
             if (o.outcome == OUT_CONTINUE) survive = true;
@@ -1605,19 +1588,19 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // + block_alloc scratch + per-lane columns: child cache (BMO_CC_MAX doubles) and the lane memory of tracing_step (BMO_LANE_MEM doubles)
     const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)(BMO_CC_MAX + BMO_LANE_MEM) * BMO_BLOCK * 8;
     void (*kern)(StepParams) = nullptr;
-    const bool asph = scene->hdr.has_asphere != 0;
+    const int ext = scene->hdr.has_asphere ? 2 : (scene->hdr.has_meniscus ? 1 : 0);  // extended-shapes level of the kernels (bmo_lane.hpp sdf_leaf)
 #if defined(BMO_DEV_RAY_LDS_ONLY)  // developer build (kernel work on one variant): everything else is refused, nothing falls back
     if constexpr (KIND == BMO_BEAM_RAY) {
-        if (!prev && !asph) kern = &step_kernel<BMO_BEAM_RAY, false, false, false>;
+        if (!prev && ext == 0) kern = &step_kernel<BMO_BEAM_RAY, 0, false>;
     }
     if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY> is compiled in");
 #else
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
-        if (prev) kern = asph ? &step_kernel_gauss<false, true, true> : &step_kernel_gauss<false, false, true>;
-        else kern = asph ? &step_kernel_gauss<false, true, false> : &step_kernel_gauss<false, false, false>;
+        if (prev) kern = ext == 2 ? &step_kernel_gauss<2, true> : (ext == 1 ? &step_kernel_gauss<1, true> : &step_kernel_gauss<0, true>);
+        else kern = ext == 2 ? &step_kernel_gauss<2, false> : (ext == 1 ? &step_kernel_gauss<1, false> : &step_kernel_gauss<0, false>);
     } else {
-        if (prev) kern = asph ? &step_kernel<KIND, false, true, true> : &step_kernel<KIND, false, false, true>;
-        else kern = asph ? &step_kernel<KIND, false, true, false> : &step_kernel<KIND, false, false, false>;
+        if (prev) kern = ext == 2 ? &step_kernel<KIND, 2, true> : (ext == 1 ? &step_kernel<KIND, 1, true> : &step_kernel<KIND, 0, true>);
+        else kern = ext == 2 ? &step_kernel<KIND, 2, false> : (ext == 1 ? &step_kernel<KIND, 1, false> : &step_kernel<KIND, 0, false>);
     }
 #endif
     if (lds_bytes > 48 * 1024)
@@ -2121,6 +2104,8 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     h.grad_h = d->grad_h;
     h.has_splitter = has_split ? 1 : 0;
     h.has_asphere = has_asph ? 1 : 0;
+    for (int i = 0; i < d->n_shapes; ++i)
+        if (d->shapes[i].kind == BMO_SHAPE_MENISCUS) h.has_meniscus = 1;
     size_t off = al(sizeof(BlobHeader));
     h.off_objects = (uint32_t)off;
     off = al(off + sizeof(bmo_object) * (size_t)d->n_objects);

@@ -401,9 +401,10 @@ BMO_HD double asph_leaf(CShape& s, CDouble* coefs, double r, double y) {
 BMO_HD Dual asph_leaf(CShape&, CDouble*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
 
 // leaf SDFs; `pt` is in the parent's frame (world, or the meniscus frame)
-// ASPH ("extended shapes"): compile the aspheric and cylinder-lens branches in.  Scenes without them run kernels
-// instantiated with ASPH = false (half the code, fewer registers).
-template <class T, bool ASPH>
+// EXT ("extended shapes" level of the kernel): 0 = the spherical / primitive leaves only; 1 = + MeniscusLensSDF; 2 = + the aspheric
+// and cylinder-lens leaves.  A scene runs the kernels of the lowest level that covers its shapes (less code, fewer registers: the
+// meniscus fold keeps a second dual number and a second frame alive around the leaf, the aspheric leaves are the largest by far).
+template <class T, int EXT>
 BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
     // every table read of this leaf in one batch (the reads are LDS round trips of ~100 cycles each: issued one by one at their
     // points of use they, not the arithmetic, set the pace of the march); `kind` comes from the caller, who has read it already
@@ -472,13 +473,13 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         T pln = (p.x + p.y) / 1.4142135623730951;  // sqrt(2)
         return jmax(box, pln);
     }
-    if constexpr (ASPH) {
+    if constexpr (EXT >= 2) {
         if (kind == BMO_SHAPE_ASPH_CONVEX || kind == BMO_SHAPE_ASPH_CONCAVE) {  // AsphericalLensSDF.jl:309-349 (op_revolve_z)
             T r = norm2(p.x, p.z) - 0.0;
             return asph_leaf(s, coefs, r, p.y);
         }
     }
-    if constexpr (ASPH) {
+    if constexpr (EXT >= 2) {
         if (kind == BMO_SHAPE_ACYL_CONVEX || kind == BMO_SHAPE_ACYL_CONCAVE) {  // AcylindricalSDF.jl:55-74, :122-141
             const double height = P2;
             T d2 = asph_distance<T>(kind == BMO_SHAPE_ACYL_CONVEX, p.z, p.y, 1 / P0, P3, P1, coefs + s.child_begin, s.child_count, s.p[4]);
@@ -514,16 +515,16 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
 
 // leaf or MeniscusLensSDF (MeniscusLensSDF.jl:42-46: max(min(convex, cylinder), -concave) in the meniscus frame): one loop so the leaf
 // switch is inlined once; the three leaf values are folded as they come (one running value live, not three)
-template <class T, bool ASPH>
+template <class T, int EXT>
 BMO_HD T sdf_simple(const SceneView& S, CShape& s, const v3<T>& pt) {
     const int kind0 = s.kind;  // (read through a wave-uniform reference: a scalar already)
-    const bool men = kind0 == BMO_SHAPE_MENISCUS;
+    const bool men = EXT >= 1 && kind0 == BMO_SHAPE_MENISCUS;
     const int nleaf = men ? 3 : 1;
     T acc = T{};
     BMO_NOUNROLL
     for (int q = 0; q < nleaf; ++q) {
         CShape& leaf = men ? S.shapes[S.children[s.child_begin + q]] : s;
-        const T v = sdf_leaf<T, ASPH>(leaf, men ? leaf.kind : kind0, men ? to_local(s, pt) : pt, S.coefs);
+        const T v = sdf_leaf<T, EXT>(leaf, men ? leaf.kind : kind0, men ? to_local(s, pt) : pt, S.coefs);
         if (q == 0) acc = v;
         else if (q == 1) acc = jmin(acc, v);
         else acc = jmax(acc, -v);
@@ -579,7 +580,7 @@ BMO_HD ShapeHead shape_head(CShape& s) {
     h.tri_begin = s.tri_begin;
     return h;
 }
-template <bool ASPH>
+template <int EXT>
 BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d3& p, int32_t& best_child, ChildCache& cc, double moved) {
 #if defined(BMO_EMU_STATS)
     ++g_emu_sdf_any;
@@ -619,7 +620,7 @@ BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d
 #if defined(BMO_EMU_STATS)
             ++g_emu_sdf_leaf;
 #endif
-            const double v = sdf_simple<double, ASPH>(S, ch, pt);
+            const double v = sdf_simple<double, EXT>(S, ch, pt);
             stored = v;
             if (q == 0) {
                 best = v;
@@ -659,14 +660,14 @@ BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d
 
 // normal3d(shape, p) of a non-union shape (UnionSDF -> normal of its argmin child, UnionSDF.jl:86-91: normal_any below):
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88).
-template <bool ASPH>
+template <int EXT>
 BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
     {
 #if defined(BMO_EMU_STATS)
         ++g_emu_normal;
 #endif
         v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
-        Dual y = sdf_simple<Dual, ASPH>(S, sh, x);
+        Dual y = sdf_simple<Dual, EXT>(S, sh, x);
         d3 n = normalize_inv(d3{y.a, y.b, y.c});
         if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
 #if defined(BMO_EMU_STATS)
@@ -684,7 +685,7 @@ BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
 #if defined(BMO_EMU_STATS)
         ++g_emu_sdf_leaf;
 #endif
-        double v = sdf_simple<double, ASPH>(S, sh, pt);
+        double v = sdf_simple<double, EXT>(S, sh, pt);
         // f(p+h) - f(p-h): the '+' value is stored first, the '-' value subtracted from it
         if (ax == 0) g0 = minus ? g0 - v : v;
         else if (ax == 1) g1 = minus ? g1 - v : v;
@@ -694,7 +695,7 @@ BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
 }
 // normal3d of shape `sid` or, for a UnionSDF, of its arg-min child (UnionSDF.jl:86-91); `kind`, `child_begin`: the shape's table fields.
 // The arg-min children of the lanes may differ: one pass per distinct shape among them (scalar scene access, file header).
-template <bool ASPH>
+template <int EXT>
 BMO_HD d3 normal_at(const SceneView& S, int32_t sid, int32_t kind, int32_t child_begin, const d3& p, int32_t best_child) {
     int32_t tid = sid;
     if (kind == BMO_SHAPE_UNION) tid = S.children[child_begin + best_child];
@@ -702,7 +703,7 @@ BMO_HD d3 normal_at(const SceneView& S, int32_t sid, int32_t kind, int32_t child
     for (bool todo = true; todo;) {
         const int32_t u = BMO_UNIFORM(tid);
         if (bmo_same_id(u, tid)) {
-            n = normal_of<ASPH>(S, S.shapes[u], p);
+            n = normal_of<EXT>(S, S.shapes[u], p);
             todo = false;
         }
     }
@@ -873,7 +874,7 @@ BMO_HD bool cull_miss(double cx, double cy, double cz, double R, const d3& pos, 
 //     it by the 1e-6 margin; t0 only grows by positive steps until the final sub-tolerance step (DESIGN.md "nearest-hit prune").
 //   * the miss cull (file header).  `calls` counts the reference's intersect3d calls, culled or not.
 // Returns the winning hit; its normal is in lane memory 0..2 (X.n is filled from there).
-template <bool ASPH, bool RETR = false>
+template <int EXT, bool RETR = false>
 BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, int32_t hint_obj, int32_t hint_shape, uint32_t& calls, ChildCache& cc,
                         const LaneMem& lm, bool probe = false, int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     enum { CLASSIFY = 0, INSIDE = 1, OUTSIDE = 2, FINAL = 3 };
@@ -1029,7 +1030,7 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                                     pos = axpy3(pos, (st & ST_BACK) ? -dist : dist, dir0);
                                     moved = fabs(dist);
                                 }
-                                const double d = sdf_any<ASPH>(S, H, s, pos, bc, cc, moved);
+                                const double d = sdf_any<EXT>(S, H, s, pos, bc, cc, moved);
                                 if (phase == OUTSIDE) {
                                     dist = d;
                                     t0 += d;
@@ -1075,7 +1076,7 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                             if (st & ST_ACTIVE) {
                                 // single normal site: the reference's normal3d, for the start classification on the surface
                                 // (dot(dir, normal) <= 0 => entering, AbstractSDF.jl:171-177) and for the winning hit
-                                const d3 n = normal_at<ASPH>(S, usid, s_kind, H.child_begin, pos, bc);
+                                const d3 n = normal_at<EXT>(S, usid, s_kind, H.child_begin, pos, bc);
                                 if ((st & 3) == FINAL) {
                                     lm.put3(0, n);
                                     st = 0;
@@ -1642,7 +1643,7 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
 // a ray is fetched when its march starts and its hit is put back when the march ends, so nothing of the beamlet but a few integers
 // is live across the three sphere-tracing marches.  On the GPU the backing store is the record itself (HBM / L2); held in
 // registers, the 3 rays + 3 hits were spilled around every march (1.5 KB of scratch per lane, 5 x the algorithmic HBM traffic).
-template <bool ASPH, bool RETR, class Rec>
+template <int EXT, bool RETR, class Rec>
 BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
                            int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     o.outcome = OUT_MISS;
@@ -1664,7 +1665,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         BMO_NOUNROLL
         for (int r = 0; r < 3; ++r) {
             const RayS ray = rec.ray(r);
-            Hit X = tracing_step<ASPH, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, lm, probing, probe_obj, false, nullptr);
+            Hit X = tracing_step<EXT, RETR>(S, ray.pos, ray.dir, hint_obj, hint_shape, calls, cc, lm, probing, probe_obj, false, nullptr);
             rec.put_hit(r, X);
             if (r == 0) {
                 sh0 = X.shape;
@@ -1797,11 +1798,11 @@ struct GaussRecLocal {
     BMO_HD int32_t hint_shape() const { return g.hint_shape; }
     BMO_HD GaussIn load() const { return g; }
 };
-template <bool ASPH, bool RETR = false>
+template <int EXT, bool RETR = false>
 BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
                        int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
     GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}};
-    gauss_step_rec<ASPH, RETR>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed);
+    gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed);
     o.Xc = rec.X[0];
     o.Xw = rec.X[1];
     o.Xd = rec.X[2];

@@ -175,7 +175,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                 ChildCache cc{ccv, 1, 0};
                 double lmv[BMO_LANE_MEM];
                 const LaneMem lm{lmv, 1};
-                X = tracing_step<true, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
+                X = tracing_step<2, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
                 if (X.shape < 0) status = (old >= 0 && missed && !fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 else {
                     interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
@@ -443,7 +443,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                 ChildCache cc{ccv, 1, 0};
                 double lmv[BMO_LANE_MEM];
                 const LaneMem lm{lmv, 1};
-                gauss_step<true, true>(S, r.g, r.o, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
+                gauss_step<2, true>(S, r.g, r.o, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
