@@ -18,6 +18,30 @@
 #include <cstdint>
 #include <limits>
 
+// ---------------------------------------------------------------------------
+// Rule-set switches for the UNPINNED third-party arithmetic (oracle/rule_table.py builds every combination and runs the transcribed
+// reference KATs, the two exact ones at their original assertions, over the product; the table is oracle/RULE_TABLE.md):
+//   BMO_RULE_SQRT0  0  sqrt(Dual(0, zeros)) keeps zero partials (ForwardDiff NaN-safe partial scaling; THE DEFAULT, see jsqrt below)
+//                   1  0 * Inf = NaN (default ForwardDiff: deriv * partials)                     [-DBMO_SQRT_PLAIN is the old spelling]
+//   BMO_RULE_TIE    0  max / min(::Dual, ::Real) at EQUAL values and equal zero signs: the Dual operand wins and keeps its partials
+//                      (DiffRules: y wins iff (y > x) | (signbit(y) < signbit(x)))                       THE DEFAULT
+//                   1  the Real operand wins the tie (zero partials), as an `ifelse(x > y, x, y)` style definition would give
+//   BMO_RULE_NORM0  0  norm(a) = sqrt(dot(a, a)) always (GeometryBasics 0.5 fixed_arrays.jl)             THE DEFAULT
+//                   1  a vector whose component VALUES are all zero returns before any sqrt, like LinearAlgebra.generic_norm2
+//                      (`iszero(maxabs) && return maxabs`): the result is the first component's abs, a Dual(0, its partials)
+#if defined(BMO_SQRT_PLAIN) && !defined(BMO_RULE_SQRT0)
+#define BMO_RULE_SQRT0 1
+#endif
+#ifndef BMO_RULE_SQRT0
+#define BMO_RULE_SQRT0 0
+#endif
+#ifndef BMO_RULE_TIE
+#define BMO_RULE_TIE 0
+#endif
+#ifndef BMO_RULE_NORM0
+#define BMO_RULE_NORM0 0
+#endif
+
 namespace jl {
 
 // ---------------------------------------------------------------------------
@@ -106,7 +130,7 @@ inline bool operator>(const Dual& a, double b) { return a.v > b; }
 inline Dual jsqrt(const Dual& a) {
     double s = std::sqrt(a.v);
     double d = 1.0 / (2.0 * s);
-#ifndef BMO_SQRT_PLAIN
+#if BMO_RULE_SQRT0 == 0
     if (!std::isfinite(d) && a.p[0] == 0 && a.p[1] == 0 && a.p[2] == 0) return Dual{s, {a.p[0], a.p[1], a.p[2]}};
 #endif
     return Dual{s, {a.p[0] * d, a.p[1] * d, a.p[2] * d}};
@@ -132,11 +156,17 @@ inline Dual jmin(const Dual& x, const Dual& y) {
 // Dual vs Real: Dual(val, dvx * partials(x))
 inline Dual jmax(const Dual& x, double y) {
     bool ywins = (y > x.v) || (std::signbit(y) < std::signbit(x.v));
+#if BMO_RULE_TIE == 1
+    if (y == x.v && std::signbit(y) == std::signbit(x.v)) ywins = true;
+#endif
     double dx = ywins ? 0.0 : 1.0;
     return Dual{jmax(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
 }
 inline Dual jmin(const Dual& x, double y) {
     bool ywins = (y < x.v) || (std::signbit(y) > std::signbit(x.v));
+#if BMO_RULE_TIE == 1
+    if (y == x.v && std::signbit(y) == std::signbit(x.v)) ywins = true;
+#endif
     double dx = ywins ? 0.0 : 1.0;
     return Dual{jmin(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
 }
@@ -218,9 +248,19 @@ template <class T> inline V2<T> operator-(const V2<T>& a, const V2<T>& b) { retu
 // dot: left fold a1*b1 + a2*b2 + a3*b3
 template <class T> inline T dot(const V3<T>& a, const V3<T>& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 template <class T> inline T dot(const V2<T>& a, const V2<T>& b) { return a.x * b.x + a.y * b.y; }
-// norm = sqrt(dot(a,a))
-template <class T> inline T norm(const V3<T>& a) { return jsqrt(dot(a, a)); }
-template <class T> inline T norm(const V2<T>& a) { return jsqrt(dot(a, a)); }
+// norm = sqrt(dot(a,a))   (BMO_RULE_NORM0 == 1: an all-zero vector returns abs of its first component before any sqrt)
+template <class T> inline T norm(const V3<T>& a) {
+#if BMO_RULE_NORM0 == 1
+    if (value(a.x) == 0 && value(a.y) == 0 && value(a.z) == 0) return jabs(a.x);
+#endif
+    return jsqrt(dot(a, a));
+}
+template <class T> inline T norm(const V2<T>& a) {
+#if BMO_RULE_NORM0 == 1
+    if (value(a.x) == 0 && value(a.y) == 0) return jabs(a.x);
+#endif
+    return jsqrt(dot(a, a));
+}
 // cross (StaticArrays / GeometryBasics): (a2*b3-a3*b2, a3*b1-a1*b3, a1*b2-a2*b1)
 inline D3 cross(const D3& a, const D3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 // normalize(::Point3) = a ./ norm(a)  (GeometryBasics 0.5)

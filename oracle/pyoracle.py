@@ -12,7 +12,7 @@ import bmo_amd as bmo
 from bmo_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liboracle.so")
+LIB = os.environ.get("BMO_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # env: a rule-set variant built by oracle/rule_table.py
 _lib = None
 
 
@@ -23,7 +23,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        if not os.path.exists(LIB) and not os.environ.get("BMO_ORACLE_LIB"):
             build()
         L = C.CDLL(LIB)
         dp = C.POINTER(C.c_double)

@@ -1,0 +1,65 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Truth table of the unpinned dual-number rules: the oracle is built once per combination of the rule switches of
+oracle/jl_math.hpp (BMO_RULE_SQRT0 x BMO_RULE_TIE x BMO_RULE_NORM0) into oracle/_variants/, and every transcribed reference KAT that
+runs on the oracle alone is run against each build — the two assertions this repo keeps relaxed (runtests.jl:157 `real(rp) ≈ 0`,
+runtests.jl:2629-2630 `direction(last(t)) == [0, 1, 0]`) at their ORIGINAL, exact form (BMO_KAT_EXACT=1).
+
+    python oracle/rule_table.py            # prints the table (and writes oracle/RULE_TABLE.md)
+
+A rule set that passes everything would be adopted by oracle and engine; the table shows there is none among these.
+"""
+import itertools
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+VAR = os.path.join(HERE, "_variants")
+KAT_FILES = ["tests/test_oracle_kat.py", "tests/test_oracle_kat2.py", "tests/test_oracle_kat3.py", "tests/test_double_gauss.py", "tests/test_asphere_system.py",
+             "tests/test_gauss_kat.py", "tests/test_photodetector.py", "tests/test_psf_readout.py", "tests/test_sources.py"]
+NAMES = {"SQRT0": ("keep zero partials", "0*Inf = NaN"), "TIE": ("Dual wins ties", "Real wins ties"), "NORM0": ("sqrt(dot)", "early return for a zero vector")}
+
+
+def build(flags, out):
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", out, os.path.join(HERE, "bmo_oracle.cpp")]
+    cmd += ["-D%s=%d" % kv for kv in flags.items()]
+    subprocess.check_call(cmd)
+
+
+def run(lib):
+    env = dict(os.environ, BMO_ORACLE_LIB=lib, BMO_KAT_EXACT="1")
+    # only what runs on the oracle alone: no GPU tests, none of the tests that compare the engine's lane code with the oracle
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "not gpu", "-k", "not emu and not lane and not engine", "-p", "no:cacheprovider"] + KAT_FILES,
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    failed = sorted(set(re.findall(r"^FAILED (\S+)", p.stdout, flags=re.M)))
+    m = re.search(r"(\d+) passed", p.stdout)
+    return int(m.group(1)) if m else 0, failed
+
+
+def main():
+    os.makedirs(VAR, exist_ok=True)
+    rows = []
+    for s0, tie, n0 in itertools.product((0, 1), (0, 1), (0, 1)):
+        flags = {"BMO_RULE_SQRT0": s0, "BMO_RULE_TIE": tie, "BMO_RULE_NORM0": n0}
+        lib = os.path.join(VAR, "liboracle_s%d_t%d_n%d.so" % (s0, tie, n0))
+        build(flags, lib)
+        passed, failed = run(lib)
+        rows.append((s0, tie, n0, passed, failed))
+        print(flags, "passed", passed, "failed", failed, flush=True)
+    out = ["# Truth table of the unpinned dual-number rules (oracle/rule_table.py)", "",
+           "Every transcribed reference KAT that runs on the oracle alone, the two relaxed ones at their original exact assertions",
+           "(`BMO_KAT_EXACT=1`: runtests.jl:157 `real(rp) ≈ 0`, runtests.jl:2629-2630 `direction(last(t)) == [0, 1, 0]`), for every",
+           "combination of the rule switches of `oracle/jl_math.hpp`.  Row 1 is the rule set oracle and engine use.", "",
+           "| sqrt(Dual(0, zeros)) | max/min(Dual, Real) at a tie | norm of a zero vector | passed | failed |", "|---|---|---|---|---|"]
+    for s0, tie, n0, passed, failed in rows:
+        out.append("| %s | %s | %s | %d | %s |" % (NAMES["SQRT0"][s0], NAMES["TIE"][tie], NAMES["NORM0"][n0], passed,
+                                                   "<br>".join(f.split("::")[-1] for f in failed) or "—"))
+    open(os.path.join(HERE, "RULE_TABLE.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

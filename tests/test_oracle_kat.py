@@ -4,6 +4,7 @@ These pin the oracle: every test cites the runtests.jl lines it
 the reference's own tolerance.  `approx(a, b)` is Julia's isapprox (rtol = sqrt(eps) unless atol).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -82,6 +83,8 @@ def test_fresnel(oracle):  # :140-195
     rs, rp, ts, tp = oracle.fresnel_coefficients(math.atan(n), n)
     # runtests.jl:157 asserts `real(rp) ≈ 0` (exact zero).  Whether the 1-ulp cancellation lands on 0 depends on the
     # libm (Julia's pure-Julia sin/cos use muladd and are not bit-identical to glibc's): here it is 1 ulp of 1.25.
+    if os.environ.get("BMO_KAT_EXACT"):  # oracle/rule_table.py: the reference's own assertion (isapprox against 0 is exact equality)
+        assert rp.real == 0
     assert abs(rp.real) <= 2.3e-16
     rs, rp, ts, tp = oracle.fresnel_coefficients(math.pi / 2, n)
     assert approx(rs.real, -1) and approx(rp.real, 1) and approx(ts.real, 0, atol=1e-300) or abs(ts.real) == 0

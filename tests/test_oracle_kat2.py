@@ -5,6 +5,7 @@ Where the reference test re-solves an already traced beam (retracing, SURVEY f1 
 through the same moved system instead: the asserted end state is the same.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -86,6 +87,8 @@ def test_cube_beamsplitter_rotated_90(oracle):  # :2619-2631
     beam = bmo.Beam([0, 0, 0], [0, 1, 0], 1e-6)
     oracle.solve_system(bmo.System([cbs]), beam)
     t = beam.children[0].rays
+    if os.environ.get("BMO_KAT_EXACT"):  # oracle/rule_table.py: the reference's own assertions (runtests.jl:2629-2630)
+        assert np.array_equal(t[-1].dir, beam.rays[0].dir) and np.array_equal(t[-1].dir, [0, 1, 0])
     assert np.abs(t[-1].dir - beam.rays[0].dir).max() <= 6.2e-17 and np.abs(t[-1].dir - np.array([0, 1, 0])).max() <= 6.2e-17
 
 
