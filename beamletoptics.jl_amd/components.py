@@ -21,6 +21,8 @@ class DiscreteRefractiveIndex:
     """Utils/RefractiveIndexUtils.jl:8-31: exact-key lookup, KeyError otherwise."""
 
     def __init__(self, lambdas, ns):
+        if len(lambdas) != len(ns):  # RefractiveIndexUtils.jl:23-25 (ArgumentError)
+            raise ValueError("Number of wavelengths must match number of ref. indices")
         self.data = {float(l): float(n) for l, n in zip(lambdas, ns)}
 
     def __call__(self, lam):

@@ -1852,6 +1852,24 @@ int bmo_cpu_refraction3d(const double* dir, const double* normal, double n1, dou
     out[2] = r.z;
     return tir ? 1 : 0;
 }
+// isentering(ray) AbstractRay.jl:234-237 (false without an intersection); refraction3d(ray, n2) :244-253 — the functions interact3d calls
+int bmo_cpu_isentering(const double* dir, const double* normal_or_null) {
+    if (!normal_or_null) return 0;
+    return dot(D3{dir[0], dir[1], dir[2]}, D3{normal_or_null[0], normal_or_null[1], normal_or_null[2]}) < 0 ? 1 : 0;
+}
+int bmo_cpu_refraction3d_ray(const double* dir, const double* isect_normal, double n_ray, double n2, double* out) {
+    Ray r;
+    r.dir = D3{dir[0], dir[1], dir[2]};
+    r.has_isect = true;
+    r.isect.n = D3{isect_normal[0], isect_normal[1], isect_normal[2]};
+    r.n = n_ray;
+    D3 o;
+    if (!refraction3d_ray(r, n2, o)) return -1;
+    out[0] = o.x;
+    out[1] = o.y;
+    out[2] = o.z;
+    return 0;
+}
 void bmo_cpu_fresnel(double theta, double n, double* out8) {
     Cx rs, rp, ts, tp;
     fresnel(theta, n, rs, rp, ts, tp);

@@ -43,6 +43,8 @@ def lib():
         L.bmo_cpu_reflection3d.argtypes = [dp, dp, dp]
         L.bmo_cpu_refraction3d.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
+        L.bmo_cpu_isentering.argtypes = [dp, dp]
+        L.bmo_cpu_refraction3d_ray.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
         L.bmo_cpu_photodetector_field.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp]
         L.bmo_cpu_gauss_parameters.argtypes = [C.c_void_p, C.c_longlong, dp, C.c_int, dp]
@@ -186,6 +188,25 @@ def refraction3d(dir, normal, n1, n2):
     if rc < 0:
         raise ValueError("dir/normal must have unit length")
     return o, bool(rc)
+
+
+def isentering(dir, normal=None):
+    """isentering(ray) AbstractRay.jl:234-237; normal = None: a ray without intersection."""
+    a, pa = _d(dir)
+    if normal is None:
+        return bool(lib().bmo_cpu_isentering(pa, None))
+    b, pb = _d(normal)
+    return bool(lib().bmo_cpu_isentering(pa, pb))
+
+
+def refraction3d_ray(dir, isect_normal, n_ray, n2):
+    """refraction3d(ray, n2) AbstractRay.jl:244-253: the normal is flipped when the ray is leaving."""
+    a, pa = _d(dir)
+    b, pb = _d(isect_normal)
+    o, po = _d(np.zeros(3))
+    if lib().bmo_cpu_refraction3d_ray(pa, pb, n_ray, n2, po) < 0:
+        raise ValueError("dir/normal must have unit length")
+    return o
 
 
 def fresnel_coefficients(theta, n):

@@ -361,3 +361,55 @@ def test_lens_from_surfaces_catalogue_shapes():  # :1393-1520 (host scene builde
     dl22 = bmo.Lens(b, c, 1.0 * mm, NBK7)
     assert abs(2 * dl21.shape.sdfs[3].hthickness - 0.001294398) <= 1e-6
     assert abs(2 * dl22.shape.sdfs[3].hthickness - 0.000723025) <= 1e-6
+
+
+# ------------------------------------------------------------------ rays: isentering / refraction3d(ray, n2) (runtests.jl:512-541)
+def test_isentering(oracle):  # :512-523
+    d = [0, 1.0, 0]
+    assert not oracle.isentering(d, [0, 1.0, 0])
+    assert oracle.isentering(d, [0, -1.0, 0])
+    assert not oracle.isentering(d, None)  # no intersection: false
+
+
+def test_refraction3d_of_a_ray_flips_the_exit_normal(oracle):  # :525-541, both assertions are exact `==` in the reference
+    n1, n2 = 1.0, 1.5
+    d = np.array([0, 1.0, 0])
+    nml = np.array([0, -1.0, 1.0])
+    nml = nml / np.sqrt((nml[0] * nml[0] + nml[1] * nml[1]) + nml[2] * nml[2])  # normalize(::Point3) = a ./ norm(a)
+    want, _ = oracle.refraction3d(d, nml, n1, n2)
+    assert np.array_equal(oracle.refraction3d_ray(d, nml, n1, n2), want)
+    flipped = nml * -1  # the ray is leaving now: refraction3d(ray, n2) flips the normal back
+    want, _ = oracle.refraction3d(d, -flipped, n1, n2)
+    assert np.array_equal(oracle.refraction3d_ray(d, flipped, n1, n2), want)
+
+
+def test_static_system_multipass_cell(oracle):  # :1063-1080: StaticSystem traces like System (System.jl:38-45)
+    mirrors, origin, d, dth, n = _multipass()
+    system = bmo.StaticSystem(mirrors)
+    beam = bmo.Beam(bmo.Ray(origin, d))
+    oracle.solve_system(system, beam, r_max=10)
+    assert len(beam.rays) == 10
+    beam = bmo.Beam(bmo.Ray(origin, d))
+    oracle.solve_system(system, beam, r_max=1000000)
+    assert len(beam.rays) == n + 1
+    assert approx(180 - math.degrees(angle3d(beam.rays[0].dir, beam.rays[-1].dir)), 2 * dth)
+    assert beam.rays[0].intersection.object is mirrors[(n + 1) // 2 + 2 - 1]
+
+
+# ------------------------------------------------------------------ refractive index utilities (runtests.jl:197-226)
+def test_sellmeier_equation():  # :204-226, RefractiveIndexUtils.jl:82-98
+    se = bmo.SellmeierEquation(0.6961663, 0.4079426, 0.8974794, 0.0684043 ** 2, 0.1162414 ** 2, 9.896161 ** 2)
+    assert abs(se(500e-9) - 1.4623) <= 3e-5  # fused silica at 500 nm
+    assert abs(se(1.0e-6) - se(1.0 * 1e-6)) <= 1e-12
+    n_vis = [se(lam * 1e-9) for lam in range(400, 701, 50)]
+    assert all(b < a for a, b in zip(n_vis, n_vis[1:]))  # normal dispersion in the visible
+
+
+def test_discrete_refractive_index():  # :207-214, RefractiveIndexUtils.jl:8-31
+    lambdas = [float(np.float32(x)) for x in (488e-9, 707e-9, 1064e-9)]
+    ref = bmo.DiscreteRefractiveIndex(lambdas, [1.6591, 1.6456, 1.6374])
+    assert ref(lambdas[1]) == 1.6456
+    with pytest.raises(KeyError):
+        ref(lambdas[0] + 1e-9)
+    with pytest.raises(ValueError):
+        bmo.DiscreteRefractiveIndex([1], [1, 2])
