@@ -353,6 +353,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         //      cannot see through (`jj`), so no address or header value of this level is held in a register (or spilled) across the
         //      marches — the ray's origin comes back from the lane memory of tracing_step, the hit's normal too.
         RetraceLane rt;
+        int32_t node = -1, k = 0;  // (two registers across the marches; read again behind them they came back from HBM: the level's records
+        d3 dir{0, 0, 0};           //  do not stay in L2 that long.  The direction is live in tracing_step anyway.)
         int32_t x_obj = -1, x_shape = -1;
         double x_t = kinf();
         bool traced = false;  // the lane ran a tracing step at this level (its record is not a pushed-but-never-traced one)
@@ -363,13 +365,16 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             const int32_t* I = C.i;
             const int32_t flags = I[I_FLAGS * cap + j];
             int32_t ho = I[I_HOBJ * cap + j], hs = I[I_HSHAPE * cap + j];
+            node = I[I_NODE * cap + j];
+            k = I[I_K * cap + j];
             if (RETR) {
-                rt = retrace_lane(P, I[I_NODE * cap + j], I[I_K * cap + j]);
+                rt = retrace_lane(P, node, k);
                 if (rt.old >= 0 && !rt.probe) ho = hs = -1;
             }
             traced = !((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed));  // else: pushed but never traced (System.jl:133)
             if (traced) {
-                const d3 pos{D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]}, dir{D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+                const d3 pos{D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
+                dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
                 // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
                 ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
 #if defined(BMO_DEV_TIMELINE)
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         asm volatile("" : "+v"(jj));
         bool survive = false, split = false, still = false, old_kids = false;
         double opl_next = 0.0, lambda = 0.0;
-        int32_t node = -1, k = 0, li = 0;
+        int32_t li = 0;
         StepOut o;
         o.outcome = OUT_MISS;
         o.status = 0;
@@ -418,8 +423,6 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             const int64_t cap = C.cap;
             double* D = C.d;
             int32_t* I = C.i;
-            node = I[I_NODE * cap + jj];
-            k = I[I_K * cap + jj];
             Hit X;
             X.t = x_t;
             X.obj = x_obj;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 X.n = lm.get3(0);
                 RayS ray;  // the interaction's share of the record
                 ray.pos = lm.get3(3);
-                ray.dir = {D[3 * cap + jj], D[4 * cap + jj], D[5 * cap + jj]};
+                ray.dir = dir;
                 ray.n = D[6 * cap + jj];
                 if (KIND == BMO_BEAM_POLARIZED)
                     for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + jj], D[(12 + 2 * c) * cap + jj]};
