@@ -197,6 +197,8 @@ struct StepParams {
     int32_t r_max;
     int32_t parity;   // step & 1: which next_count slot this launch fills
     OldSolution old;  // RETR kernels only
+    double* gstage;      // GaussianBeamlet kernels: [42][gstage_cap] staging planes of the rays a step produces (GaussRecDev)
+    int64_t gstage_cap;
     uint8_t* wave_last;  // [waves of the launch]: the last in-place level each wave reached (nullptr: nobody will read the log)
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
@@ -288,6 +290,9 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
 #ifndef BMO_MIN_WAVES
 #define BMO_MIN_WAVES 3  /* <= 168 VGPRs.  Round 3: with the scene tables read by scalar loads tracing_step is spill-free at 168 registers and 3 waves/SIMD
                             beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5 (profiles/r03_ab_scalar_scene.txt); 4 (128) still spills in the march */
+#endif
+#ifndef BMO_MIN_WAVES_GAUSS
+#define BMO_MIN_WAVES_GAUSS 3
 #endif
 // One launch advances every active beam by up to P.n_fuse bounces.  Bounce 0 reads its records from P.cur; a lane that goes
 // on writes its next record IN PLACE (same slot j) into P.inner[b] and traces it in the same launch — no compaction, no host
@@ -575,6 +580,19 @@ struct GaussRecDev {
     const NodeArrays& nodes;
     int64_t cap, j;
     int32_t node;
+    double* G;     // staging of the rays the step produces: [42][gcap], planes 7 r + c the next ray r, 21 + 7 r + c its reflected child
+    int64_t gcap;
+    __device__ void put_ray(int base, const RayS& x) const {
+        G[(base + 0) * gcap + j] = x.pos.x;
+        G[(base + 1) * gcap + j] = x.pos.y;
+        G[(base + 2) * gcap + j] = x.pos.z;
+        G[(base + 3) * gcap + j] = x.dir.x;
+        G[(base + 4) * gcap + j] = x.dir.y;
+        G[(base + 5) * gcap + j] = x.dir.z;
+        G[(base + 6) * gcap + j] = x.n;
+    }
+    __device__ void put_next(int r, const RayS& x) const { put_ray(7 * r, x); }
+    __device__ void put_refl(int r, const RayS& x) const { put_ray(21 + 7 * r, x); }
     __device__ RayS ray(int r) const {
         const int64_t b = 11 * (int64_t)r;
         RayS x;
@@ -632,7 +650,7 @@ struct GaussRecDevNoHint : GaussRecDev {
 };
 
 template <int EXT, bool RETR>
-__global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(StepParams P) {
+__global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
     char* scratch = lds;
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             rt = retrace_lane(P, node, k);
             no_hint = rt.old >= 0 && !rt.probe;
         }
-        GaussRecDev rec{D, I, P.nodes, cap, j, node};
+        GaussRecDev rec{D, I, P.nodes, cap, j, node, P.gstage, P.gstage_cap};
         if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
             status = BMO_NODE_RMAX;
             rec.clear_hits();
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
             const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
             if (RETR && no_hint) {
-                GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node}};
+                GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, P.gstage, P.gstage_cap}};
                 gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
             } else {
                 gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
@@ -701,26 +719,20 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
     }
     const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
     const int64_t ncap = P.nxt.cap;
-    auto write_next = [&](int64_t slot, const RayS& c, const RayS& w, const RayS& d, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl,
-                          double lenA, double lenB, double oplC, double oplW, double oplD) {
+    // the rays of the next record come back from the staging planes (gbase 0: next rays, 21: reflected children), seven doubles at a time
+    auto write_next = [&](int64_t slot, int gbase, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,
+                          double oplW, double oplD) {
         if (slot >= ncap) {
             atomicAdd(&P.ctr->overflow, 1ull);
             return;
         }
         double* D = P.nxt.d;
         int32_t* I = P.nxt.i;
-        auto wr = [&](int bs, const RayS& r) {
-            D[(bs + 0) * ncap + slot] = r.pos.x;
-            D[(bs + 1) * ncap + slot] = r.pos.y;
-            D[(bs + 2) * ncap + slot] = r.pos.z;
-            D[(bs + 3) * ncap + slot] = r.dir.x;
-            D[(bs + 4) * ncap + slot] = r.dir.y;
-            D[(bs + 5) * ncap + slot] = r.dir.z;
-            D[(bs + 6) * ncap + slot] = r.n;
-        };
-        wr(0, c);
-        wr(11, w);
-        wr(22, d);
+        const double* G = P.gstage;
+        const int64_t gcap = P.gstage_cap;
+        BMO_NOUNROLL
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 7; ++c) D[(11 * r + c) * ncap + slot] = G[(gbase + 7 * r + c) * gcap + j];
         D[33 * ncap + slot] = lenA;
         D[34 * ncap + slot] = lenB;
         D[35 * ncap + slot] = oplC;
@@ -740,7 +752,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             if (k + 1 < rt.old_n) fl = 0;
             else ho = hs = -1;
         }
-        write_next(slot, o.nc, o.nw, o.nd, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+        write_next(slot, 0, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
     }
     if (split) {
         const int r = prefix_rank(al.m_split);
@@ -773,8 +785,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel_gauss(St
             }
             const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
             // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
-            write_next(slot, o.nc, o.nw, o.nd, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
-            write_next(slot + 1, o.rc, o.rw, o.rd, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
+            write_next(slot, 0, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
+            write_next(slot + 1, 21, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
         } else {
             atomicAdd(&P.ctr->overflow, 1ull);
         }
@@ -1621,6 +1633,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         fuse_max = MAX_FUSE;
         if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(MAX_FUSE, atoi(e)));
     }
+    DevBuf gstage;
+    int64_t gstage_cap = 0;
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
     while (cur.count > 0) {
         const int64_t m = cur.count;
@@ -1661,7 +1675,17 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             blocks_after[q + 1] = R->arena.size();
         }
         if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
+        // (Gaussian) staging planes for this launch's output rays: one buffer for the whole solve, grown when a launch has more records
+        // than any before it (the previous launch has completed by then: its block goes back to the pool at once)
+        if (KIND == BMO_BEAM_GAUSSIAN && m > gstage_cap) {
+            PoolHold::Now at_once;
+            gstage.release();
+            gstage_cap = ((m + m / 8 + 1) & ~(int64_t)1);
+            if ((rc = gstage.alloc((size_t)gstage_cap * 42 * 8))) return rc;
+        }
         StepParams P;
+        P.gstage = (double*)gstage.p;
+        P.gstage_cap = gstage_cap;
         P.hdr = scene->hdr;
         P.blob = dblob;
         P.blob_bytes = blob_bytes;

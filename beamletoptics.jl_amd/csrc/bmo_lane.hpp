@@ -1533,8 +1533,8 @@ struct GaussOut {
     Hit Xc, Xw, Xd;                // filled by the struct-backed wrapper only
     int32_t hit_obj, hit_shape;    // object / shape the chief ray hit (-1: none)
     int32_t hint_obj, hint_shape;
-    RayS nc, nw, nd;  // next segment, or transmitted child
-    RayS rc, rw, rd;  // reflected child
+    RayS nc, nw, nd;  // next segment, or transmitted child   } filled by the struct-backed wrapper (gauss_step) only: the record-backed
+    RayS rc, rw, rd;  // reflected child                      } form hands the rays to Rec::put_next / put_refl as they are computed
     int det_slot, n_det;
     double* det;  // destination of the detector record(s) of this beamlet, 3 x 9 doubles (the node's hit slot): written in place
     double child_w0, child_l0;
@@ -1740,17 +1740,13 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         so.det = o.det + 9 * r;
         interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, entering_hint);
         o.status |= so.status;
+        // the next segment (or the transmitted child) and the reflected child of ray r go to the record's sink at once: held in
+        // registers until the slot allocation, the six rays of a beamlet were what the 168-register kernel spilled (round 3)
+        rec.put_next(r, so.next);
+        if (so.outcome == OUT_SPLIT) rec.put_refl(r, so.refl);
         if (r == 0) {
-            o.nc = so.next;
-            o.rc = so.refl;
             o.hint_obj = so.hint_obj;
             o.hint_shape = so.hint_shape;
-        } else if (r == 1) {
-            o.nw = so.next;
-            o.rw = so.refl;
-        } else {
-            o.nd = so.next;
-            o.rd = so.refl;
         }
         if (so.det_slot >= 0) {
             o.det_slot = so.det_slot;
@@ -1790,6 +1786,9 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
 struct GaussRecLocal {
     const GaussIn& g;
     Hit X[3];
+    RayS nxt[3], rfl[3];
+    BMO_HD void put_next(int r, const RayS& x) { nxt[r] = x; }
+    BMO_HD void put_refl(int r, const RayS& x) { rfl[r] = x; }
     BMO_HD RayS ray(int r) const { return pick_ray(r, g.c, g.w, g.d); }
     BMO_HD void put_hit(int r, const Hit& x) { X[r] = x; }
     BMO_HD Hit hit(int r) const { return X[r]; }
@@ -1801,8 +1800,14 @@ struct GaussRecLocal {
 template <int EXT, bool RETR = false>
 BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
                        int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
-    GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}};
+    GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}, {}, {}};
     gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed);
+    o.nc = rec.nxt[0];
+    o.nw = rec.nxt[1];
+    o.nd = rec.nxt[2];
+    o.rc = rec.rfl[0];
+    o.rw = rec.rfl[1];
+    o.rd = rec.rfl[2];
     o.Xc = rec.X[0];
     o.Xw = rec.X[1];
     o.Xd = rec.X[2];
