@@ -134,14 +134,26 @@ struct Chunk {
     int64_t count;
     // In-place level `level` (1..) of a fused launch: the slots of wave w (64 consecutive slots) hold records or hole marks only if that
     // wave got as far as this level, wl[w] >= level; what lies beyond was never written.  wl == nullptr: every slot below count is a record.
+    // A launch over few records spreads them thinly — wave w owns the 2^wl_shift consecutive slots from w << wl_shift (StepParams::lane_shift).
     const uint8_t* wl = nullptr;
     int32_t level = 0;
+    int32_t wl_shift = 6;
 };
 // node id of record j of a chunk of the log, -1 where there is none (a beam that ended earlier, or a level its wave did not reach)
 __device__ __forceinline__ int32_t chunk_node(const Chunk& c, int64_t j) {
-    if (c.wl && c.level > (int32_t)c.wl[j >> 6]) return -1;
+    if (c.wl && c.level > (int32_t)c.wl[j >> c.wl_shift]) return -1;
     return c.i[I_NODE * c.cap + j];
 }
+
+// interact's sink for the ray that goes on (bmo_lane.hpp NextInOut): the seven slots of the lane memory
+struct NextInLaneMem {
+    const LaneMem& lm;
+    __device__ void put(const d3& pos, const d3& dir, double n) const {
+        lm.put3(0, pos);
+        lm.put3(3, dir);
+        lm.m[6 * lm.stride] = n;
+    }
+};
 
 struct Counters {  // device-resident, one per trace
     // records written to the next chunk.  Two slots: step s accumulates into slot s & 1 and clears the other one for step s + 1
@@ -151,6 +163,7 @@ struct Counters {  // device-resident, one per trace
     unsigned long long max_depth;  // deepest beam-tree level created so far (sizes the sort keys of the final ordering)
     unsigned long long overflow;
     unsigned long long max_level[2];  // deepest in-place level any wave of the launch reached (slots used like next_count's)
+    unsigned long long inwave[2];     // reflected children pushed from inside the fused loops of the launch (slots used like next_count's)
 };
 
 struct NodeArrays {
@@ -200,6 +213,14 @@ struct StepParams {
     double* gstage;      // GaussianBeamlet kernels: [42][gstage_cap] staging planes of the rays a step produces (GaussRecDev)
     int64_t gstage_cap;
     uint8_t* wave_last;  // [waves of the launch]: the last in-place level each wave reached (nullptr: nobody will read the log)
+    // Records per wave = 2^lane_shift (6: every lane has one).  A level of a wave takes as long as its slowest lane, and the launches of a
+    // deep beam tree's tail have far fewer records than the device has lanes: spread over more waves (the upper lanes idle) a slow march
+    // holds up 2^lane_shift - 1 neighbours instead of 63.  Record j lives in lane j & (2^lane_shift - 1) of wave j >> lane_shift.
+    int32_t lane_shift;
+    // Room in P.nxt (and in the node arrays) for beam-splitter children made INSIDE the fused loop: a splitting lane goes on with its transmitted
+    // child in place and pushes the reflected one to the next launch, as long as the launch has pushed fewer than this many; after that a
+    // split ends the wave's loop as it always did (block_alloc has room for two records per lane whatever happened before).
+    int64_t inwave_cap;
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
 #endif
@@ -300,7 +321,10 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
 // loop ends for a WAVE when one of its lanes splits (children need the slot allocation below) or when none goes on; the four waves
 // of a workgroup run their loops independently and meet at the block-wide allocation.  Survivors of the last fused bounce and
 // beam-splitter children are compacted into P.nxt as before.
-template <int KIND, int EXT, bool RETR>
+// INW: beam splitters are handled inside the fused loop (the launches of a beam tree's tail: fewer launches, no launch waits for the
+// slowest march of every generation); without it a split ends the wave's loop and both children wait for the next launch, which costs
+// less register room — the large launches of the BASELINE configs run 2 - 7 % faster that way (profiles/r03_ab_inwave.txt).
+template <int KIND, int EXT, bool RETR, bool INW>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
@@ -308,13 +332,15 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr->next_count[P.parity ^ 1] = 0;
         P.ctr->max_level[P.parity ^ 1] = 0;
+        P.ctr->inwave[P.parity ^ 1] = 0;
     }
     using L = Layout<KIND>;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
-    const bool valid = j < m;
+    const bool valid = j < m && lane_id() < (1 << P.lane_shift);
 #if defined(BMO_DEV_TIMELINE)
-    if (P.tl && (threadIdx.x & 63) == 0 && (j & ~(int64_t)63) < P.cur.count) P.tl[2 * (j >> 6)] = wall_clock64();
+    if (P.tl && (threadIdx.x & 63) == 0 && (gwave << P.lane_shift) < P.cur.count) P.tl[2 * gwave] = wall_clock64();
 #endif
 
     // A lane carries nothing but `alive` from one fused bounce to the next: it writes its next record and reads it back at the
@@ -450,7 +476,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 li = P.nodes.li[node];
                 lambda = P.nodes.lambda[node];
                 o.det = P.nodes.hit + (int64_t)node * 9;  // a detector hit ends the beam: its record goes straight to the node's slot
-                interact<KIND>(S, ray, X, li, lambda, opl_acc, o);
+                // (the ray that goes on is put into the lane memory — hit normal, origin and plate mark there are spent — as soon as a
+                //  branch of the interaction has it, and comes back from there when its record is written: bmo_lane.hpp NextInOut)
+                interact<KIND>(S, ray, X, li, lambda, opl_acc, o, NextInLaneMem{lm});
                 status = o.status;
                 if (o.outcome == OUT_CONTINUE) {
                     survive = true;
@@ -489,11 +517,82 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             tk_last = t;
         }
 #endif
+        const int64_t ncap = P.nxt.cap;
+        auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
+            if (slot >= ncap) {
+                atomicAdd(&P.ctr->overflow, 1ull);
+                return;
+            }
+            write_ray(P.nxt, slot, r, nd, kk, ho, hs, fl, opl);
+        };
+        // the two children of a splitting lane: nodes cn (transmitted) and cn + 1 (reflected)
+        auto make_children = [&](int64_t cn) {
+            const unsigned long long pkey = P.nodes.key[node];
+            const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
+            const int32_t root = P.nodes.root[node];
+            atomicMax(&P.ctr->max_depth, depth + 1ull);
+            for (int w = 0; w < 2; ++w) {
+                const int64_t c = cn + w;
+                P.nodes.root[c] = root;
+                P.nodes.parent[c] = node;
+                P.nodes.nseg[c] = 1;
+                P.nodes.status[c] = 0;
+                P.nodes.li[c] = li;
+                P.nodes.lambda[c] = lambda;
+                P.nodes.hit_det[c] = -1;
+                P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
+                if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
+            }
+        };
+        const int32_t child_flags = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
+        auto next_ray = [&]() {
+            RayS r = o.next;  // (E0 of a PolarizedRay stays where it is)
+            r.pos = lm.get3(0);
+            r.dir = lm.get3(3);
+            r.n = lm.m[6 * lm.stride];
+            return r;
+        };
         bool go_on = b + 1 < P.n_fuse;
         // wave-uniform decisions: every wave runs its own fused loop (no workgroup barrier per level: the four waves of a workgroup used to
-        // wait for the slowest of them at every bounce); the workgroup meets again at block_alloc below
-        if (go_on) go_on = !__any(split ? 1 : 0);
-        if (go_on) go_on = __any(survive ? 1 : 0) != 0;
+        // wait for the slowest of them at every bounce); the workgroup meets again at block_alloc below.
+        // Beam splitters first, wherever in the loop they are met: one reservation per wave — a run of node pairs and a run of slots in
+        // P.nxt — and, while the launch has room for it (inwave_cap), the splitting lane goes on with its transmitted child in place and
+        // only the reflected one waits for the next launch; otherwise both wait there and the wave's loop ends.
+        const unsigned long long m_split = INW ? __ballot(split) : 0ull;
+        bool kid_here = false;  // this lane goes on with its transmitted child
+        if (!INW) {
+            if (go_on) go_on = !__any(split ? 1 : 0);
+        } else if (m_split) {
+            const int ns = __popcll(m_split);
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            if (go_on) {
+                if (lane_id() == 0) r0 = atomicAdd(&P.ctr->inwave[P.parity], (unsigned long long)ns);
+                r0 = __shfl(r0, 0);
+                if ((int64_t)(r0 + ns) > P.inwave_cap) go_on = false;
+            }
+            if (lane_id() == 0) {
+                r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? ns : 2 * ns));
+                r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
+            }
+            r1 = __shfl(r1, 0);
+            r2 = __shfl(r2, 0);
+            if (split) {
+                const int r = prefix_rank(m_split);
+                const int64_t cn = (int64_t)r2 + 2 * r;
+                if (cn + 1 < P.nodes.cap) {
+                    make_children(cn);
+                    const Chunk T = go_on ? P.inner[b] : P.nxt;  // (wave-uniform)
+                    const int64_t ts = go_on ? jj : (int64_t)r1 + 2 * r;
+                    if (ts < T.cap) write_ray(T, ts, next_ray(), (int32_t)cn, 0, -1, -1, child_flags, opl_next);
+                    else atomicAdd(&P.ctr->overflow, 1ull);
+                    write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
+                    kid_here = go_on;
+                } else {
+                    atomicAdd(&P.ctr->overflow, 1ull);
+                }
+            }
+        }
+        if (go_on) go_on = __any((survive || kid_here) ? 1 : 0) != 0;
         if (go_on) {
             // go on in place: the next record of a surviving lane is written to the same slot of the next inner chunk
             const Chunk N = P.inner[b];
@@ -501,8 +600,8 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 if (alive && survive) {
                     int32_t fl, ho, hs;
                     next_header(fl, ho, hs);
-                    write_ray(N, jj, o.next, node, k + 1, ho, hs, fl, opl_next);
-                } else {
+                    write_ray(N, jj, next_ray(), node, k + 1, ho, hs, fl, opl_next);
+                } else if (!kid_here) {
                     N.i[I_NODE * N.cap + jj] = -1;  // no record of this beam at this level
                     alive = false;
                 }
@@ -513,55 +612,31 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         // ---- last fused bounce of this wave (kept inside the loop so that o.next / o.refl die here instead of staying live
         //      across the march of the next iteration): note how far the wave got — the in-place levels beyond are never written and
         //      never read (Chunk::wl) —, then compact into the next launch's chunk
-        if (P.wave_last && lane_id() == 0) P.wave_last[j >> 6] = (uint8_t)b;
+        if (P.wave_last && lane_id() == 0) P.wave_last[gwave] = (uint8_t)b;
 #if defined(BMO_DEV_TIMELINE)
-        if (P.tl && (threadIdx.x & 63) == 0 && (j & ~(int64_t)63) < P.cur.count) {  // (tail waves of the grid have no slot in the timeline)
-            P.tl[2 * (j >> 6) + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
-            const int64_t nw = (P.cur.count + 63) / 64;
+        if (P.tl && (threadIdx.x & 63) == 0 && (gwave << P.lane_shift) < P.cur.count) {  // (tail waves of the grid have no slot in the timeline)
+            P.tl[2 * gwave + 1] = wall_clock64();  // before the workgroup barrier of block_alloc
+            const int64_t nw = (P.cur.count + (1 << P.lane_shift) - 1) >> P.lane_shift;
             atomicAdd(&P.tl[2 * nw + 0], tk0);
             atomicAdd(&P.tl[2 * nw + 1], tk1);
             atomicAdd(&P.tl[2 * nw + 2], tk2);
         }
 #endif
-        const SlotAlloc al = block_alloc(survive, split, calls, P, scratch, b);
-        const int64_t ncap = P.nxt.cap;
-        auto write_next = [&](int64_t slot, const RayS& r, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double opl) {
-            if (slot >= ncap) {
-                atomicAdd(&P.ctr->overflow, 1ull);
-                return;
-            }
-            write_ray(P.nxt, slot, r, nd, kk, ho, hs, fl, opl);
-        };
+        const SlotAlloc al = block_alloc(survive, !INW && split, calls, P, scratch, b);
         if (survive) {  // survivors first
             const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
             int32_t fl, ho, hs;
             next_header(fl, ho, hs);
-            write_next(slot, o.next, node, k + 1, ho, hs, fl, opl_next);
+            write_next(slot, next_ray(), node, k + 1, ho, hs, fl, opl_next);
         }
-        if (split) {  // then 2 children per splitting lane
+        if (!INW && split) {  // then 2 children per splitting lane
             const int r = prefix_rank(al.m_split);
             const int64_t slot = (int64_t)al.child_base + 2 * r;
             const int64_t cn = (int64_t)al.node_base + 2 * r;
             if (cn + 1 < P.nodes.cap) {
-                const unsigned long long pkey = P.nodes.key[node];
-                const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
-                const int32_t root = P.nodes.root[node];
-                atomicMax(&P.ctr->max_depth, depth + 1ull);
-                for (int w = 0; w < 2; ++w) {
-                    const int64_t c = cn + w;
-                    P.nodes.root[c] = root;
-                    P.nodes.parent[c] = node;
-                    P.nodes.nseg[c] = 1;
-                    P.nodes.status[c] = 0;
-                    P.nodes.li[c] = li;
-                    P.nodes.lambda[c] = lambda;
-                    P.nodes.hit_det[c] = -1;
-                    P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
-                    if (RETR) P.nodes.old[c] = old_kids ? P.old.first_child[rt.old] + w : -1;  // children!: the stored child is re-walked
-                }
-                const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
-                write_next(slot, o.next, (int32_t)cn, 0, -1, -1, fl, opl_next);
-                write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, fl, opl_next);
+                make_children(cn);
+                write_next(slot, next_ray(), (int32_t)cn, 0, -1, -1, child_flags, opl_next);
+                write_next(slot + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
             } else {
                 atomicAdd(&P.ctr->overflow, 1ull);
             }
@@ -1602,11 +1677,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     }
     // + block_alloc scratch + per-lane columns: child cache (BMO_CC_MAX doubles) and the lane memory of tracing_step (BMO_LANE_MEM doubles)
     const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)(BMO_CC_MAX + BMO_LANE_MEM) * BMO_BLOCK * 8;
-    void (*kern)(StepParams) = nullptr;
+    void (*kern)(StepParams) = nullptr, (*kern_inw)(StepParams) = nullptr;  // kern_inw: the Beam kernels' variant with in-loop beam splitters
     const int ext = scene->hdr.has_asphere ? 2 : (scene->hdr.has_meniscus ? 1 : 0);  // extended-shapes level of the kernels (bmo_lane.hpp sdf_leaf)
 #if defined(BMO_DEV_RAY_LDS_ONLY)  // developer build (kernel work on one variant): everything else is refused, nothing falls back
     if constexpr (KIND == BMO_BEAM_RAY) {
-        if (!prev && ext == 0) kern = &step_kernel<BMO_BEAM_RAY, 0, false>;
+        if (!prev && ext == 0) kern = &step_kernel<BMO_BEAM_RAY, 0, false, false>, kern_inw = &step_kernel<BMO_BEAM_RAY, 0, false, true>;
     }
     if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY> is compiled in");
 #else
@@ -1614,12 +1689,16 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if (prev) kern = ext == 2 ? &step_kernel_gauss<2, true> : (ext == 1 ? &step_kernel_gauss<1, true> : &step_kernel_gauss<0, true>);
         else kern = ext == 2 ? &step_kernel_gauss<2, false> : (ext == 1 ? &step_kernel_gauss<1, false> : &step_kernel_gauss<0, false>);
     } else {
-        if (prev) kern = ext == 2 ? &step_kernel<KIND, 2, true> : (ext == 1 ? &step_kernel<KIND, 1, true> : &step_kernel<KIND, 0, true>);
-        else kern = ext == 2 ? &step_kernel<KIND, 2, false> : (ext == 1 ? &step_kernel<KIND, 1, false> : &step_kernel<KIND, 0, false>);
+        if (prev) kern = ext == 2 ? &step_kernel<KIND, 2, true, false> : (ext == 1 ? &step_kernel<KIND, 1, true, false> : &step_kernel<KIND, 0, true, false>);
+        else kern = ext == 2 ? &step_kernel<KIND, 2, false, false> : (ext == 1 ? &step_kernel<KIND, 1, false, false> : &step_kernel<KIND, 0, false, false>);
+        if (prev) kern_inw = ext == 2 ? &step_kernel<KIND, 2, true, true> : (ext == 1 ? &step_kernel<KIND, 1, true, true> : &step_kernel<KIND, 0, true, true>);
+        else kern_inw = ext == 2 ? &step_kernel<KIND, 2, false, true> : (ext == 1 ? &step_kernel<KIND, 1, false, true> : &step_kernel<KIND, 0, false, true>);
     }
 #endif
-    if (lds_bytes > 48 * 1024)
+    if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (kern_inw) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_inw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
 
     int64_t n_nodes = n;
     double kernel_ms = 0;
@@ -1640,17 +1719,33 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         const int64_t m = cur.count;
         static const double keep_hi = getenv("BMO_KEEP_HI") ? atof(getenv("BMO_KEEP_HI")) : 0.9, keep_lo = getenv("BMO_KEEP_LO") ? atof(getenv("BMO_KEEP_LO")) : 0.6;
         static const int fuse_mid = getenv("BMO_FUSE_MID") ? atoi(getenv("BMO_FUSE_MID")) : 2, fuse_lo = getenv("BMO_FUSE_LO") ? atoi(getenv("BMO_FUSE_LO")) : 1;
-        int n_fuse = keep_ratio >= keep_hi ? fuse_max : (keep_ratio >= keep_lo ? std::min(fuse_mid, fuse_max) : std::min(fuse_lo, fuse_max));
+        // records per wave (StepParams::lane_shift): thinned out when the launch has fewer waves than the device has SIMDs to spare
+        int lane_shift = 6;
+        if (KIND != BMO_BEAM_GAUSSIAN) {
+            static const int64_t thin_waves = getenv("BMO_THIN_WAVES") ? atoll(getenv("BMO_THIN_WAVES")) : 1024;
+            while (lane_shift > 0 && ((m + (1ll << (lane_shift - 1)) - 1) >> (lane_shift - 1)) <= thin_waves) lane_shift -= 1;
+        }
+        // Beam kernels: every launch fuses all its levels, whatever share of its beams ends, and handles its beam splitters in the loop
+        // (step_kernel<.., INW>): holes cost lane time, launches cost the wait for the slowest march of every generation, and the second
+        // is the dearer one — the vignetted bundle takes 2 launches and 14 ms this way, 12 launches and 23 ms with the keep-ratio rule of
+        // round 2, which BMO_INWAVE_MAX (largest launch treated like this, in records) brings back for launches above it.
+        static const int64_t inwave_max = getenv("BMO_INWAVE_MAX") ? atoll(getenv("BMO_INWAVE_MAX")) : INT64_MAX;
+        const bool tail = KIND != BMO_BEAM_GAUSSIAN && m <= inwave_max;
+        int n_fuse = tail ? fuse_max : keep_ratio >= keep_hi ? fuse_max : (keep_ratio >= keep_lo ? std::min(fuse_mid, fuse_max) : std::min(fuse_lo, fuse_max));
         // the in-place levels of a launch are allocated up front: at most 24 GB of them (2^24 beams: 8 levels)
         if (keep_log) n_fuse = (int)std::min<int64_t>(n_fuse, 1 + (int64_t)(((size_t)24 << 30) / ((size_t)std::max<int64_t>(m, 1) * rec_bytes)));
+        const int64_t n_waves = (m + (1ll << lane_shift) - 1) >> lane_shift;
+        const unsigned n_blocks = (unsigned)((n_waves + BMO_BLOCK / 64 - 1) / (BMO_BLOCK / 64));
         Chunk nxt, inner[MAX_FUSE - 1];
         // the next launch's chunk first, then the in-place levels: the levels no wave reaches go back to the arena after the launch
-        if ((rc = new_chunk(has_split ? 2 * m : m, nxt))) return rc;
+        // (in-loop beam splitters of the Beam kernels: room for up to m reflected children more, StepParams::inwave_cap)
+        const int64_t inwave_cap = (has_split && kern_inw && n_fuse > 1 && tail) ? m : 0;
+        if ((rc = new_chunk((has_split ? 2 * m : m) + inwave_cap, nxt))) return rc;
         uint8_t* wl = nullptr;
         if (keep_log && n_fuse > 1) {
             auto b = std::make_unique<DevBuf>();
             // one byte per wave of the GRID, not of the batch: the tail waves of the last workgroup (no record, j >= m) note their level too
-            if ((rc = b->alloc((size_t)((m + BMO_BLOCK - 1) / BMO_BLOCK) * (BMO_BLOCK / 64)))) return rc;
+            if ((rc = b->alloc((size_t)n_blocks * (BMO_BLOCK / 64)))) return rc;
             wl = static_cast<uint8_t*>(b->p);
             R->wave_last.push_back(std::move(b));
         }
@@ -1671,10 +1766,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             inner[q].count = m;  // same slot numbering as cur; records of beams that ended earlier are marked node = -1
             inner[q].wl = wl;
             inner[q].level = q + 1;
+            inner[q].wl_shift = lane_shift;
             top_after[q + 1] = top;
             blocks_after[q + 1] = R->arena.size();
         }
-        if (has_split && (rc = grow_nodes(n_nodes + 2 * m))) return rc;
+        if (has_split && (rc = grow_nodes(n_nodes + 2 * m + 2 * inwave_cap))) return rc;
         // (Gaussian) staging planes for this launch's output rays: one buffer for the whole solve, grown when a launch has more records
         // than any before it (the previous launch has completed by then: its block goes back to the pool at once)
         if (KIND == BMO_BEAM_GAUSSIAN && m > gstage_cap) {
@@ -1701,16 +1797,18 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.parity = steps & 1;
         P.old = old_tab;
         P.wave_last = wl;
+        P.lane_shift = lane_shift;
+        P.inwave_cap = inwave_cap;
 #if defined(BMO_DEV_TIMELINE)  // developer builds, BMO_TIMELINE=1: how many waves are at work over the course of every launch
         DevBuf tl_buf;
         P.tl = nullptr;
         if (getenv("BMO_TIMELINE")) {
-            if ((rc = tl_buf.alloc((size_t)((m + 63) / 64) * 16 + 64))) return rc;
+            if ((rc = tl_buf.alloc((size_t)n_waves * 16 + 64))) return rc;
             HIP_TRY(hipMemsetAsync(tl_buf.p, 0, tl_buf.bytes, stream));
             P.tl = (unsigned long long*)tl_buf.p;
         }
 #endif
-        DBG("step %d launching m=%lld", steps, (long long)m);
+        DBG("step %d launching m=%lld, %d records per wave", steps, (long long)m, 1 << lane_shift);
         // launch timing: one event pair per step out of a cached pool, read after the loop (nothing but the counter read-back
         // sits between two launches)
         while ((int)ctxp->step_ev.size() < 2 * (steps + 1)) {
@@ -1719,14 +1817,14 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             ctxp->step_ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((m + BMO_BLOCK - 1) / BMO_BLOCK)), dim3(BMO_BLOCK), lds_bytes, stream, P);
+        hipLaunchKernelGGL(inwave_cap > 0 ? kern_inw : kern, dim3(n_blocks), dim3(BMO_BLOCK), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps + 1], stream));
         HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
 #if defined(BMO_DEV_TIMELINE)
         if (P.tl) {
-            const size_t nw = (size_t)((m + 63) / 64);
+            const size_t nw = (size_t)n_waves;
             std::vector<unsigned long long> t(2 * nw + 3);
             HIP_TRY(hipMemcpy(t.data(), P.tl, nw * 16 + 24, hipMemcpyDeviceToHost));
             {
@@ -1753,7 +1851,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
 #endif
         const unsigned long long produced = h_ctr.next_count[steps & 1];
-        DBG("step %d done next=%llu nodes=%llu", steps, produced, h_ctr.node_count);
+        DBG("step %d done next=%llu nodes=%llu deepest in-place level %llu of %d", steps, produced, h_ctr.node_count, h_ctr.max_level[steps & 1], n_fuse);
         steps += 1;
         if (h_ctr.overflow) return fail(BMO_ERR_INTERNAL, "queue overflow (internal capacity bound violated)");
         if (keep_log) {

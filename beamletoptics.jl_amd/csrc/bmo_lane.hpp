@@ -1267,9 +1267,21 @@ BMO_HD d3 hit_point(const RayS& r, double t) { return axpy3(r.pos, t, r.dir); }
 //   split     ThinBeamsplitter.jl:73-115, PlateBeamsplitter.jl:189-228, CubeBeamsplitter.jl:63-92
 //   detectors Spotdetector.jl:50-61, PSFDetector.jl:77-89     polarizer PolarizationFilter.jl:31-48
 // `opl_before` = optical path length of the beam (incl. parents) up to the START of this segment.
-template <int KIND>
+// Where the geometric part of the ray that goes on (OUT_CONTINUE: the new segment, OUT_SPLIT: the transmitted child) is put the moment
+// it is known.  NextInOut leaves it in StepOut::next; the Beam step kernels hand in the lane memory instead (bmo_engine.hip NextInLaneMem):
+// every branch of the interaction stores its result there at once, so that nothing of it is held in registers — or spilled — across the
+// wave's decision what to do with the record.
+struct NextInOut {
+    StepOut& o;
+    BMO_HD void put(const d3& pos, const d3& dir, double n) const {
+        o.next.pos = pos;
+        o.next.dir = dir;
+        o.next.n = n;
+    }
+};
+template <int KIND, class NextSink>
 BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, double lambda, double opl_before, StepOut& o,
-                     int ent_override = -1) {
+                     const NextSink& sink, int ent_override = -1) {
     CObject& ob = S.objects[X.obj];
     o.outcome = OUT_STOP;
     o.hint_obj = o.hint_shape = -1;
@@ -1394,9 +1406,7 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
                 return;
             }
         }
-        o.next.pos = hp;
-        o.next.dir = nd;
-        o.next.n = n_out;
+        sink.put(hp, nd, n_out);
         o.hint_obj = ho;
         o.hint_shape = hs;
         if (force_hobj >= 0) {
@@ -1409,8 +1419,9 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
     if (action == A_SPLIT) {
         // children via the public Ray ctor: dir normalised, n = 1 (ThinBeamsplitter.jl:73-106, Rays.jl:32-42)
         const d3 rdir = reflection3d(ray.dir, X.n);
-        o.next.pos = o.refl.pos = hp;
-        o.next.n = o.refl.n = 1.0;
+        o.refl.pos = hp;
+        o.refl.n = 1.0;
+        double next_n = 1.0;
         if (KIND == BMO_BEAM_POLARIZED) {
             BMO_NOUNROLL
             for (int w = 0; w < 2; ++w) {
@@ -1425,9 +1436,9 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
                 }
             }
         }
-        o.next.dir = normalize_div(ray.dir);
+        d3 next_dir = normalize_div(ray.dir);
         o.refl.dir = normalize_div(rdir);
-        if (KIND == BMO_BEAM_POLARIZED && !(e0_orthogonal(o.next.dir, o.next.E0) && e0_orthogonal(o.refl.dir, o.refl.E0))) {
+        if (KIND == BMO_BEAM_POLARIZED && !(e0_orthogonal(next_dir, o.next.E0) && e0_orthogonal(o.refl.dir, o.refl.E0))) {
             o.status |= BMO_NODE_ERR_ORTHO;
             return;
         }
@@ -1445,14 +1456,15 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
                 o.status |= BMO_NODE_ERR_UNIT;
                 return;
             }
-            o.next.n = nt;
+            next_n = nt;
             o.refl.n = nr;
-            o.next.dir = normalize_div(nd);  // direction! AbstractRay.jl:83-86
+            next_dir = normalize_div(nd);  // direction! AbstractRay.jl:83-86
         } else if (split_mode == 2) {  // CubeBeamsplitter.jl:78-84
             const double ng = n_medium(S, ob.medium[0], li);
-            o.next.n = ng;
+            next_n = ng;
             o.refl.n = ng;
         }
+        sink.put(hp, next_dir, next_n);
         o.outcome = OUT_SPLIT;
         return;
     }
@@ -1502,10 +1514,8 @@ BMO_HD void interact(const SceneView& S, const RayS& ray, const Hit& X, int li, 
             o.status |= BMO_NODE_BLOCKED;
             return;
         }
-        o.next.pos = hp;
-        o.next.dir = ray.dir;
-        o.next.n = ray.n;
-        if (!e0_orthogonal(o.next.dir, o.next.E0)) {
+        sink.put(hp, ray.dir, ray.n);
+        if (!e0_orthogonal(ray.dir, o.next.E0)) {
             o.status |= BMO_NODE_ERR_ORTHO;
             return;
         }
@@ -1738,7 +1748,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         StepOut so;
         so.status = 0;
         so.det = o.det + 9 * r;
-        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, entering_hint);
+        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, NextInOut{so}, entering_hint);
         o.status |= so.status;
         // the next segment (or the transmitted child) and the reflected child of ray r go to the record's sink at once: held in
         // registers until the slot allocation, the six rays of a beamlet were what the 168-register kernel spilled (round 3)

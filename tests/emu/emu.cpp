@@ -178,7 +178,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                 X = tracing_step<2, true>(S, r.ray.pos, r.ray.dir, hobj, hshape, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
                 if (X.shape < 0) status = (old >= 0 && missed && !fresh_allowed) ? BMO_NODE_RMAX : BMO_NODE_MISS;
                 else {
-                    interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o);
+                    interact<KIND>(S, r.ray, X, nd.li, nd.lambda, r.opl, o, NextInOut{o});
                     status = o.status;
                     opl_next = r.opl + X.t * r.ray.n;
                     if (o.outcome == OUT_CONTINUE) survive = true;
