@@ -202,7 +202,8 @@ struct StepParams {
     uint32_t blob_bytes;
     int32_t use_lds;
     Chunk cur, nxt;
-    Chunk inner[MAX_FUSE - 1];   // in-place levels 1..n_fuse-1 of this launch (Beam kernels; capacity >= cur.count, same slot numbering as cur)
+    Chunk inner[MAX_FUSE - 1];   // in-place levels 1..n_fuse-1 of this launch (capacity >= cur.count, same slot numbering as cur); the GaussianBeamlet
+                                 // kernels use one more, inner[n_fuse - 1], for the rays of the last fused level (step_kernel_gauss)
     int32_t n_fuse;   // bounces per launch, 1..MAX_FUSE
     Counters* ctr;
     unsigned long long* call_shards;  // 64 counters, 128 B apart: reference intersect3d call count (metric numerator)
@@ -210,7 +211,7 @@ struct StepParams {
     int32_t r_max;
     int32_t parity;   // step & 1: which next_count slot this launch fills
     OldSolution old;  // RETR kernels only
-    double* gstage;      // GaussianBeamlet kernels: [42][gstage_cap] staging planes of the rays a step produces (GaussRecDev)
+    double* gstage;      // GaussianBeamlet kernels: [21][gstage_cap] staging planes of the reflected child's rays (GaussRecDev)
     int64_t gstage_cap;
     uint8_t* wave_last;  // [waves of the launch]: the last in-place level each wave reached (nullptr: nobody will read the log)
     // Records per wave = 2^lane_shift (6: every lane has one).  A level of a wave takes as long as its slowest lane, and the launches of a
@@ -655,19 +656,30 @@ struct GaussRecDev {
     const NodeArrays& nodes;
     int64_t cap, j;
     int32_t node;
-    double* G;     // staging of the rays the step produces: [42][gcap], planes 7 r + c the next ray r, 21 + 7 r + c its reflected child
+    double* N;     // the next level's record planes (same slot j): the rays the step produces for the beamlet that goes on are written
+    int64_t ncap;  // straight into their record, planes 11 r + c
+    double* G;     // staging of the reflected child's rays: [21][gcap], planes 7 r + c
     int64_t gcap;
-    __device__ void put_ray(int base, const RayS& x) const {
-        G[(base + 0) * gcap + j] = x.pos.x;
-        G[(base + 1) * gcap + j] = x.pos.y;
-        G[(base + 2) * gcap + j] = x.pos.z;
-        G[(base + 3) * gcap + j] = x.dir.x;
-        G[(base + 4) * gcap + j] = x.dir.y;
-        G[(base + 5) * gcap + j] = x.dir.z;
-        G[(base + 6) * gcap + j] = x.n;
+    __device__ void put_next(int r, const RayS& x) const {
+        const int64_t b = 11 * (int64_t)r;
+        N[(b + 0) * ncap + j] = x.pos.x;
+        N[(b + 1) * ncap + j] = x.pos.y;
+        N[(b + 2) * ncap + j] = x.pos.z;
+        N[(b + 3) * ncap + j] = x.dir.x;
+        N[(b + 4) * ncap + j] = x.dir.y;
+        N[(b + 5) * ncap + j] = x.dir.z;
+        N[(b + 6) * ncap + j] = x.n;
     }
-    __device__ void put_next(int r, const RayS& x) const { put_ray(7 * r, x); }
-    __device__ void put_refl(int r, const RayS& x) const { put_ray(21 + 7 * r, x); }
+    __device__ void put_refl(int r, const RayS& x) const {
+        const int64_t b = 7 * (int64_t)r;
+        G[(b + 0) * gcap + j] = x.pos.x;
+        G[(b + 1) * gcap + j] = x.pos.y;
+        G[(b + 2) * gcap + j] = x.pos.z;
+        G[(b + 3) * gcap + j] = x.dir.x;
+        G[(b + 4) * gcap + j] = x.dir.y;
+        G[(b + 5) * gcap + j] = x.dir.z;
+        G[(b + 6) * gcap + j] = x.n;
+    }
     __device__ RayS ray(int r) const {
         const int64_t b = 11 * (int64_t)r;
         RayS x;
@@ -699,6 +711,20 @@ struct GaussRecDev {
     }
     __device__ int32_t hint_obj() const { return I[I_HOBJ * cap + j]; }
     __device__ int32_t hint_shape() const { return I[I_HSHAPE * cap + j]; }
+    __device__ GaussAcc acc() const {
+        GaussAcc a;
+        a.lenA = D[33 * cap + j];
+        a.lenB = D[34 * cap + j];
+        a.oplC = D[35 * cap + j];
+        a.oplW = D[36 * cap + j];
+        a.oplD = D[37 * cap + j];
+        a.li = nodes.li[node];
+        a.lambda = nodes.lambda[node];
+        a.l0 = nodes.aux[(int64_t)node * 4 + 0];
+        a.w0 = nodes.aux[(int64_t)node * 4 + 1];
+        a.E0 = {nodes.aux[(int64_t)node * 4 + 2], nodes.aux[(int64_t)node * 4 + 3]};
+        return a;
+    }
     __device__ GaussIn load() const {
         GaussIn g;
         g.c = ray(0);
@@ -724,147 +750,214 @@ struct GaussRecDevNoHint : GaussRecDev {
     __device__ int32_t hint_shape() const { return -1; }
 };
 
+// One launch advances every active beamlet by up to P.n_fuse bounces, like step_kernel: level b reads its records from C = (b == 0 ? P.cur :
+// P.inner[b - 1]) at slot j and writes the rays of the beamlet that goes on IN PLACE into P.inner[b] at the same slot, as gauss_step_rec
+// produces them (no staging copy, no compaction between the levels; P.inner has n_fuse entries here — the last one only holds the rays of
+// the last fused level until they are compacted into P.nxt).  Beam splitters are handled in the loop: the transmitted child goes on in
+// place, the reflected child's rays wait in the staging planes and are pushed to P.nxt (StepParams::inwave_cap).
 template <int EXT, bool RETR>
 __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_gauss(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
     char* scratch = lds;
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->next_count[P.parity ^ 1] = 0;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t m = P.cur.count, cap = P.cur.cap;
-    const bool valid = j < m;
-    bool survive = false, split = false;
-    int32_t node = -1, k = 0;
-    GaussOut o;
-    o.outcome = OUT_MISS;
-    uint32_t calls = 0;
-    RetraceLane rt;
-    bool still = false, old_kids = false;
-    if (valid) {
-        double* D = P.cur.d;
-        int32_t* I = P.cur.i;
-        node = I[I_NODE * cap + j];
-        k = I[I_K * cap + j];
-        const int32_t flags = I[I_FLAGS * cap + j];
-        int status = 0;
-        o.hit_obj = o.hit_shape = -1;
-        o.det_slot = -1;
-        o.det = P.nodes.hit + (int64_t)node * 27;  // a detector hit ends the beamlet: its records go straight to the node's slot
-        bool no_hint = false;
-        if (RETR) {
-            rt = retrace_lane(P, node, k);
-            no_hint = rt.old >= 0 && !rt.probe;
-        }
-        GaussRecDev rec{D, I, P.nodes, cap, j, node, P.gstage, P.gstage_cap};
-        if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
-            status = BMO_NODE_RMAX;
-            rec.clear_hits();
-        } else {
-            ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
-            const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
-            if (RETR && no_hint) {
-                GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, P.gstage, P.gstage_cap}};
-                gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
-            } else {
-                gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
-            }
-            status = o.status;
-            if (o.outcome == OUT_CONTINUE) survive = true;
-            else if (o.outcome == OUT_SPLIT) {
-                split = true;
-                status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
-            } else if (o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
-        }
-        I[I_OBJ * cap + j] = o.hit_obj;
-        I[I_SHAPE * cap + j] = o.hit_shape;
-        if (RETR) {
-            still = rt.old >= 0 && rt.probe && !rt.missed;
-            old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
-            if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
-            // a split before the end of the stored path: the reference sizes the children (w0, E0) with the stale tail still attached
-            // to the beamlet (gauss_parameters(gauss, length(gauss)), ThinBeamsplitter.jl:125); here they are evaluated at the split
-            if (split && still && k + 1 < rt.old_n) status |= BMO_NODE_RETRACE_STALE;
-            if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
-        }
-        if (!survive) {
-            P.nodes.nseg[node] = k + 1;
-            P.nodes.status[node] = status;
-            if (o.det_slot >= 0 && !(flags & F_DEAD)) P.nodes.hit_det[node] = o.det_slot;
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.ctr->next_count[P.parity ^ 1] = 0;
+        P.ctr->max_level[P.parity ^ 1] = 0;
+        P.ctr->inwave[P.parity ^ 1] = 0;
     }
-    const SlotAlloc al = block_alloc(survive, split, calls, P, scratch);
+    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const int64_t j = (gwave << P.lane_shift) + lane_id();
+    const int64_t m = P.cur.count;
+    const bool valid = j < m && lane_id() < (1 << P.lane_shift);
+    bool alive = valid;
+    uint32_t calls = 0;
     const int64_t ncap = P.nxt.cap;
-    // the rays of the next record come back from the staging planes (gbase 0: next rays, 21: reflected children), seven doubles at a time
-    auto write_next = [&](int64_t slot, int gbase, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,
+    // accumulators and header of a record whose rays are in place already
+    auto write_tail = [&](const Chunk& T, int64_t slot, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,
                           double oplW, double oplD) {
+        const int64_t tcap = T.cap;
+        double* D = T.d;
+        int32_t* I = T.i;
+        D[33 * tcap + slot] = lenA;
+        D[34 * tcap + slot] = lenB;
+        D[35 * tcap + slot] = oplC;
+        D[36 * tcap + slot] = oplW;
+        D[37 * tcap + slot] = oplD;
+        I[I_NODE * tcap + slot] = nd;
+        I[I_K * tcap + slot] = kk;
+        I[I_HOBJ * tcap + slot] = ho;
+        I[I_HSHAPE * tcap + slot] = hs;
+        I[I_FLAGS * tcap + slot] = fl;
+    };
+    // a whole record in P.nxt: rays from `src` (plane r * rstride + c of capacity scap, at slot j), then accumulators and header
+    auto write_next = [&](int64_t slot, const double* src, int64_t scap, int rstride, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA,
+                          double lenB, double oplC, double oplW, double oplD) {
         if (slot >= ncap) {
             atomicAdd(&P.ctr->overflow, 1ull);
             return;
         }
         double* D = P.nxt.d;
-        int32_t* I = P.nxt.i;
-        const double* G = P.gstage;
-        const int64_t gcap = P.gstage_cap;
         BMO_NOUNROLL
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 7; ++c) D[(11 * r + c) * ncap + slot] = G[(gbase + 7 * r + c) * gcap + j];
-        D[33 * ncap + slot] = lenA;
-        D[34 * ncap + slot] = lenB;
-        D[35 * ncap + slot] = oplC;
-        D[36 * ncap + slot] = oplW;
-        D[37 * ncap + slot] = oplD;
-        I[I_NODE * ncap + slot] = nd;
-        I[I_K * ncap + slot] = kk;
-        I[I_HOBJ * ncap + slot] = ho;
-        I[I_HSHAPE * ncap + slot] = hs;
-        I[I_FLAGS * ncap + slot] = fl;
+            for (int c = 0; c < 7; ++c) D[(11 * r + c) * ncap + slot] = src[(int64_t)(rstride * r + c) * scap + j];
+        write_tail(P.nxt, slot, nd, kk, ho, hs, fl, lenA, lenB, oplC, oplW, oplD);
     };
-    if (survive) {
-        const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
-        int32_t fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
-        int32_t ho = o.hint_obj, hs = o.hint_shape;
-        if (RETR && still) {
-            if (k + 1 < rt.old_n) fl = 0;
-            else ho = hs = -1;
+    int b = 0;
+    for (;;) {
+        const Chunk C = b == 0 ? P.cur : P.inner[b - 1];
+        const Chunk N = P.inner[b];
+        const int64_t cap = C.cap;
+        bool survive = false, split = false;
+        int32_t node = -1, k = 0;
+        GaussOut o;
+        o.outcome = OUT_MISS;
+        RetraceLane rt;
+        bool still = false, old_kids = false;
+        if (alive) {
+            double* D = C.d;
+            int32_t* I = C.i;
+            node = I[I_NODE * cap + j];
+            k = I[I_K * cap + j];
+            const int32_t flags = I[I_FLAGS * cap + j];
+            int status = 0;
+            o.hit_obj = o.hit_shape = -1;
+            o.det_slot = -1;
+            o.det = P.nodes.hit + (int64_t)node * 27;  // a detector hit ends the beamlet: its records go straight to the node's slot
+            bool no_hint = false;
+            if (RETR) {
+                rt = retrace_lane(P, node, k);
+                no_hint = rt.old >= 0 && !rt.probe;
+            }
+            GaussRecDev rec{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap};
+            if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
+                status = BMO_NODE_RMAX;
+                rec.clear_hits();
+            } else {
+                ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
+                const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
+                if (RETR && no_hint) {
+                    GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap}};
+                    gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                } else {
+                    gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                }
+                status = o.status;
+                if (o.outcome == OUT_CONTINUE) survive = true;
+                else if (o.outcome == OUT_SPLIT) {
+                    split = true;
+                    status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
+                } else if (o.outcome == OUT_STOP) status |= BMO_NODE_STOPPED;
+            }
+            I[I_OBJ * cap + j] = o.hit_obj;
+            I[I_SHAPE * cap + j] = o.hit_shape;
+            if (RETR) {
+                still = rt.old >= 0 && rt.probe && !rt.missed;
+                old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
+                if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+                // a split before the end of the stored path: the reference sizes the children (w0, E0) with the stale tail still attached
+                // to the beamlet (gauss_parameters(gauss, length(gauss)), ThinBeamsplitter.jl:125); here they are evaluated at the split
+                if (split && still && k + 1 < rt.old_n) status |= BMO_NODE_RETRACE_STALE;
+                if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
+            }
+            if (!survive) {
+                P.nodes.nseg[node] = k + 1;
+                P.nodes.status[node] = status;
+                if (o.det_slot >= 0 && !(flags & F_DEAD)) P.nodes.hit_det[node] = o.det_slot;
+            }
         }
-        write_next(slot, 0, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
-    }
-    if (split) {
-        const int r = prefix_rank(al.m_split);
-        const int64_t slot = (int64_t)al.child_base + 2 * r;
-        const int64_t cn = (int64_t)al.node_base + 2 * r;
-        if (cn + 1 < P.nodes.cap) {
-            const unsigned long long pkey = P.nodes.key[node];
-            const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
-            const int32_t root = P.nodes.root[node];
-            atomicMax(&P.ctr->max_depth, depth + 1ull);
-            for (int w = 0; w < 2; ++w) {
-                const int64_t c = cn + w;
-                P.nodes.root[c] = root;
-                P.nodes.parent[c] = node;
-                P.nodes.nseg[c] = 1;
-                P.nodes.status[c] = 0;
-                P.nodes.li[c] = P.nodes.li[node];
-                P.nodes.lambda[c] = P.nodes.lambda[node];
-                P.nodes.hit_det[c] = -1;
-                P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
-                P.nodes.aux[c * 4 + 0] = o.child_l0;
-                P.nodes.aux[c * 4 + 1] = o.child_w0;
-                P.nodes.aux[c * 4 + 2] = w == 0 ? o.Et.re : o.Er.re;
-                P.nodes.aux[c * 4 + 3] = w == 0 ? o.Et.im : o.Er.im;
-                if (RETR) {
-                    const int32_t oc = old_kids ? P.old.first_child[rt.old] + w : -1;
-                    P.nodes.old[c] = oc;
-                    if (oc >= 0) P.nodes.aux[c * 4 + 1] = P.old.aux[(int64_t)oc * 4 + 1];  // _modify_beam_head! keeps the stored w0 (Gaussian.jl:154-161)
+        // header of the record that follows a surviving bounce
+        auto next_header = [&](int32_t& fl, int32_t& ho, int32_t& hs) {
+            fl = (k + 2 < P.r_max) ? 0 : F_DEAD;
+            ho = o.hint_obj;
+            hs = o.hint_shape;
+            if (RETR && still) {
+                if (k + 1 < rt.old_n) fl = 0;
+                else ho = hs = -1;
+            }
+        };
+        bool go_on = b + 1 < P.n_fuse;
+        // beam splitters, wherever in the loop they are met (see step_kernel): one reservation per wave
+        const unsigned long long m_split = __ballot(split);
+        bool kid_here = false;
+        if (m_split) {
+            const int ns = __popcll(m_split);
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            if (go_on) {
+                if (lane_id() == 0) r0 = atomicAdd(&P.ctr->inwave[P.parity], (unsigned long long)ns);
+                r0 = __shfl(r0, 0);
+                if ((int64_t)(r0 + ns) > P.inwave_cap) go_on = false;
+            }
+            if (lane_id() == 0) {
+                r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? ns : 2 * ns));
+                r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
+            }
+            r1 = __shfl(r1, 0);
+            r2 = __shfl(r2, 0);
+            if (split) {
+                const int r = prefix_rank(m_split);
+                const int64_t cn = (int64_t)r2 + 2 * r;
+                if (cn + 1 < P.nodes.cap) {
+                    const unsigned long long pkey = P.nodes.key[node];
+                    const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
+                    const int32_t root = P.nodes.root[node];
+                    atomicMax(&P.ctr->max_depth, depth + 1ull);
+                    for (int w = 0; w < 2; ++w) {
+                        const int64_t c = cn + w;
+                        P.nodes.root[c] = root;
+                        P.nodes.parent[c] = node;
+                        P.nodes.nseg[c] = 1;
+                        P.nodes.status[c] = 0;
+                        P.nodes.li[c] = P.nodes.li[node];
+                        P.nodes.lambda[c] = P.nodes.lambda[node];
+                        P.nodes.hit_det[c] = -1;
+                        P.nodes.key[c] = ((depth + 1) << 32) | (((path << 1) | (unsigned long long)w) & 0xFFFFFFFFull);
+                        P.nodes.aux[c * 4 + 0] = o.child_l0;
+                        P.nodes.aux[c * 4 + 1] = o.child_w0;
+                        P.nodes.aux[c * 4 + 2] = w == 0 ? o.Et.re : o.Er.re;
+                        P.nodes.aux[c * 4 + 3] = w == 0 ? o.Et.im : o.Er.im;
+                        if (RETR) {
+                            const int32_t oc = old_kids ? P.old.first_child[rt.old] + w : -1;
+                            P.nodes.old[c] = oc;
+                            if (oc >= 0) P.nodes.aux[c * 4 + 1] = P.old.aux[(int64_t)oc * 4 + 1];  // _modify_beam_head! keeps the stored w0 (Gaussian.jl:154-161)
+                        }
+                    }
+                    const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
+                    // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
+                    if (go_on) write_tail(N, j, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);  // (its rays are in place)
+                    else write_next((int64_t)r1 + 2 * r, N.d, N.cap, 11, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
+                    write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, P.gstage, P.gstage_cap, 7, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC,
+                               0.0, 0.0);
+                    kid_here = go_on;
+                } else {
+                    atomicAdd(&P.ctr->overflow, 1ull);
                 }
             }
-            const int32_t fl = ((RETR && old_kids) || 1 < P.r_max) ? 0 : F_DEAD;
-            // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
-            write_next(slot, 0, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
-            write_next(slot + 1, 21, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
-        } else {
-            atomicAdd(&P.ctr->overflow, 1ull);
         }
+        if (go_on) go_on = __any((survive || kid_here) ? 1 : 0) != 0;
+        if (go_on) {
+            if (valid) {
+                if (alive && survive) {
+                    int32_t fl, ho, hs;
+                    next_header(fl, ho, hs);
+                    write_tail(N, j, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+                } else if (!kid_here) {
+                    N.i[I_NODE * N.cap + j] = -1;  // no record of this beamlet at this level
+                    alive = false;
+                }
+            }
+            b += 1;
+            continue;
+        }
+        // ---- last fused bounce of this wave
+        if (P.wave_last && lane_id() == 0) P.wave_last[gwave] = (uint8_t)b;
+        const SlotAlloc al = block_alloc(survive, false, calls, P, scratch, b);
+        if (survive) {
+            const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
+            int32_t fl, ho, hs;
+            next_header(fl, ho, hs);
+            write_next(slot, N.d, N.cap, 11, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+        }
+        return;
     }
 }
 
@@ -1705,13 +1798,12 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     int steps = 0;
     // bounces per launch (Beam kernels): fewer launches, host round trips and scene stagings; holes instead of compaction inside a
     // launch.  BMO_FUSE=1 restores one launch per bounce level.
-    int fuse_max = 1;
-    if (KIND != BMO_BEAM_GAUSSIAN) {
-        // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by
-        // another 1-3 %, and 32 beat 16 by 1-2.5 % (config C2 reaches its splitter, level 17, in the first launch: 2 launches instead of 3)
-        fuse_max = MAX_FUSE;
-        if (const char* e = getenv("BMO_FUSE")) fuse_max = std::max(1, std::min(MAX_FUSE, atoi(e)));
-    }
+    // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by
+    // another 1-3 %, and 32 beat 16 by 1-2.5 % (config C2 reaches its splitter, level 17, in the first launch: 2 launches instead of 3).
+    // The GaussianBeamlet kernels need one in-place chunk more than they fuse levels (step_kernel_gauss): one level fewer.
+    constexpr bool GAUSS = KIND == BMO_BEAM_GAUSSIAN;
+    int fuse_max = GAUSS ? MAX_FUSE - 1 : MAX_FUSE;
+    if (const char* e = getenv(GAUSS ? "BMO_FUSE_GAUSS" : "BMO_FUSE")) fuse_max = std::max(1, std::min(fuse_max, atoi(e)));
     DevBuf gstage;
     int64_t gstage_cap = 0;
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
@@ -1721,7 +1813,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         static const int fuse_mid = getenv("BMO_FUSE_MID") ? atoi(getenv("BMO_FUSE_MID")) : 2, fuse_lo = getenv("BMO_FUSE_LO") ? atoi(getenv("BMO_FUSE_LO")) : 1;
         // records per wave (StepParams::lane_shift): thinned out when the launch has fewer waves than the device has SIMDs to spare
         int lane_shift = 6;
-        if (KIND != BMO_BEAM_GAUSSIAN) {
+        {
             static const int64_t thin_waves = getenv("BMO_THIN_WAVES") ? atoll(getenv("BMO_THIN_WAVES")) : 1024;
             while (lane_shift > 0 && ((m + (1ll << (lane_shift - 1)) - 1) >> (lane_shift - 1)) <= thin_waves) lane_shift -= 1;
         }
@@ -1730,7 +1822,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         // is the dearer one — the vignetted bundle takes 2 launches and 14 ms this way, 12 launches and 23 ms with the keep-ratio rule of
         // round 2, which BMO_INWAVE_MAX (largest launch treated like this, in records) brings back for launches above it.
         static const int64_t inwave_max = getenv("BMO_INWAVE_MAX") ? atoll(getenv("BMO_INWAVE_MAX")) : INT64_MAX;
-        const bool tail = KIND != BMO_BEAM_GAUSSIAN && m <= inwave_max;
+        const bool tail = m <= inwave_max;
         int n_fuse = tail ? fuse_max : keep_ratio >= keep_hi ? fuse_max : (keep_ratio >= keep_lo ? std::min(fuse_mid, fuse_max) : std::min(fuse_lo, fuse_max));
         // the in-place levels of a launch are allocated up front: at most 24 GB of them (2^24 beams: 8 levels)
         if (keep_log) n_fuse = (int)std::min<int64_t>(n_fuse, 1 + (int64_t)(((size_t)24 << 30) / ((size_t)std::max<int64_t>(m, 1) * rec_bytes)));
@@ -1739,7 +1831,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         Chunk nxt, inner[MAX_FUSE - 1];
         // the next launch's chunk first, then the in-place levels: the levels no wave reaches go back to the arena after the launch
         // (in-loop beam splitters of the Beam kernels: room for up to m reflected children more, StepParams::inwave_cap)
-        const int64_t inwave_cap = (has_split && kern_inw && n_fuse > 1 && tail) ? m : 0;
+        const int64_t inwave_cap = (has_split && (kern_inw || GAUSS) && n_fuse > 1 && tail) ? m : 0;
         if ((rc = new_chunk((has_split ? 2 * m : m) + inwave_cap, nxt))) return rc;
         uint8_t* wl = nullptr;
         if (keep_log && n_fuse > 1) {
@@ -1752,14 +1844,16 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         size_t top_after[MAX_FUSE], blocks_after[MAX_FUSE];  // arena state behind nxt [0] and behind every in-place level [q + 1]
         top_after[0] = top;
         blocks_after[0] = R->arena.size();
-        for (int q = 0; q + 1 < n_fuse; ++q) {
-            if (!keep_log && q > 0) {
-                inner[q] = inner[0];  // nobody reads the log: a lane's in-place record is dead once it has been read back, one chunk serves all levels
+        for (int q = 0; q < (GAUSS ? n_fuse : n_fuse - 1); ++q) {
+            if (!keep_log && q > (GAUSS ? 1 : 0)) {
+                // nobody reads the log: a lane's in-place record is dead once it has been read back, one chunk serves all levels (a beamlet's
+                // step writes its next rays while the hits of the level it reads are still being filled in: two chunks, taken in turns)
+                inner[q] = inner[GAUSS ? (q & 1) : 0];
                 continue;
             }
             if ((rc = new_chunk(m, inner[q]))) {
                 if (rc != BMO_ERR_OOM || q == 0) return rc;
-                n_fuse = q + 1;  // no room for this many in-place levels: fuse the ones that fit (the launch before fused fewer, too)
+                n_fuse = GAUSS ? q : q + 1;  // no room for this many in-place levels: fuse the ones that fit (the launch before fused fewer, too)
                 rc = BMO_OK;
                 break;
             }
@@ -1771,13 +1865,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             blocks_after[q + 1] = R->arena.size();
         }
         if (has_split && (rc = grow_nodes(n_nodes + 2 * m + 2 * inwave_cap))) return rc;
-        // (Gaussian) staging planes for this launch's output rays: one buffer for the whole solve, grown when a launch has more records
+        // (Gaussian) staging planes for the reflected children's rays of this launch: one buffer for the whole solve, grown when a launch has more records
         // than any before it (the previous launch has completed by then: its block goes back to the pool at once)
         if (KIND == BMO_BEAM_GAUSSIAN && m > gstage_cap) {
             PoolHold::Now at_once;
             gstage.release();
             gstage_cap = ((m + m / 8 + 1) & ~(int64_t)1);
-            if ((rc = gstage.alloc((size_t)gstage_cap * 42 * 8))) return rc;
+            if ((rc = gstage.alloc((size_t)gstage_cap * 21 * 8))) return rc;
         }
         StepParams P;
         P.gstage = (double*)gstage.p;
@@ -1788,7 +1882,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.use_lds = use_lds;
         P.cur = cur;
         P.nxt = nxt;
-        for (int q = 0; q < MAX_FUSE - 1; ++q) P.inner[q] = q + 1 < n_fuse ? inner[q] : Chunk{nullptr, nullptr, 0, 0};
+        for (int q = 0; q < MAX_FUSE - 1; ++q) P.inner[q] = q < (GAUSS ? n_fuse : n_fuse - 1) ? inner[q] : Chunk{nullptr, nullptr, 0, 0};
         P.n_fuse = n_fuse;
         P.ctr = d_ctr;
         P.call_shards = static_cast<unsigned long long*>(shard_buf.p);
@@ -1860,14 +1954,15 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             for (int q = 0; q < used; ++q) R->chunks.push_back(inner[q]);
             // the levels behind them were never touched: their room goes back to the arena (allocation is a bump, so everything
             // allocated after the last level in use belongs to them)
-            if (used + 1 < n_fuse) {
+            if (used < (GAUSS ? n_fuse : n_fuse - 1)) {  // (the GaussianBeamlet kernels' extra level is always given back)
                 PoolHold::Now at_once;  // (the launch has completed: nothing in flight touches these blocks)
                 while (R->arena.size() > blocks_after[used]) R->arena.pop_back();
                 top = top_after[used];
             }
         } else {  // the launch above has completed (counter read-back): its input and in-place levels are dead
             drop_chunk(cur);
-            if (n_fuse > 1) drop_chunk(inner[0]);
+            if (GAUSS || n_fuse > 1) drop_chunk(inner[0]);
+            if (GAUSS && n_fuse > 1) drop_chunk(inner[1]);
         }
         shrink_last(nxt, (int64_t)produced);
         keep_ratio = (double)std::min<unsigned long long>(produced, (unsigned long long)m) / (double)m;
@@ -2132,9 +2227,13 @@ int bmo_version(void) { return BMO_ABI_VERSION; }
 #if !defined(BMO_SOURCE_HASH)
 #define BMO_SOURCE_HASH ""
 #endif
-// (the marker in front lets the build script read the hash out of the file without loading the library)
+#if !defined(BMO_FLAGS_HASH)
+#define BMO_FLAGS_HASH ""
+#endif
+// (the markers in front let the build script read the hashes out of the file without loading the library; the second one is the hash of
+//  the compiler flags, so that a change of flags rebuilds the library too)
 const char* bmo_source_hash(void) {
-    static const char tagged[] = "BMO_SOURCE_HASH=" BMO_SOURCE_HASH;
+    static const char tagged[] = "BMO_SOURCE_HASH=" BMO_SOURCE_HASH "\0BMO_FLAGS_HASH=" BMO_FLAGS_HASH;
     return tagged + 16;
 }
 const char* bmo_last_error(void) { return g_err.c_str(); }

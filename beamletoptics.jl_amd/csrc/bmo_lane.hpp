@@ -1538,6 +1538,26 @@ struct GaussIn {
     cx E0;
     int li;
 };
+// The accumulators and beam constants of a beamlet record, without its rays
+struct GaussAcc {
+    double lenA, lenB, oplC, oplW, oplD;
+    double lambda, l0, w0;
+    cx E0;
+    int li;
+};
+// interact's sink (NextInOut) of a beamlet's ray r: straight into the record
+template <class Rec>
+struct GaussNextSink {
+    Rec& rec;
+    int r;
+    BMO_HD void put(const d3& pos, const d3& dir, double n) const {
+        RayS x;
+        x.pos = pos;
+        x.dir = dir;
+        x.n = n;
+        rec.put_next(r, x);
+    }
+};
 struct GaussOut {
     int outcome, status;
     Hit Xc, Xw, Xd;                // filled by the struct-backed wrapper only
@@ -1715,44 +1735,56 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         o.status = BMO_NODE_GAUSS_DIVERGED;
         return;
     }
-    const GaussIn g = rec.load();  // rays and accumulators, from here on
+    // From here on the record is read piece by piece, each where it is needed (the accumulators now, a ray when its interaction comes, all
+    // three once more for a splitter's waist): the whole beamlet held in registers across the three interactions is what the fused
+    // 168-register kernel spilled.
+    const GaussAcc a = rec.acc();
     const Hit Xc = rec.hit(0);     // t and normal of the chief's hit
     const double tw = rec.hit(1).t, td = rec.hit(2).t;
     const int32_t oid = ob0;
     CObject& ob = S.objects[oid];
     if (ob.kind == BMO_OBJ_PHOTODETECTOR) {  // Photodetector.jl:69-107: record the hit (field read-out is a separate pass), stop
+        const RayS c = rec.ray(0);
         o.det_slot = ob.detector;
-        for (int c = 0; c < 27; ++c) o.det[c] = 0.0;
-        o.det[0] = fabs(dot3(g.c.dir, Xc.n));  // proj = abs(dot(d0, normal3d(ray_int)))
+        for (int q = 0; q < 27; ++q) o.det[q] = 0.0;
+        o.det[0] = fabs(dot3(c.dir, Xc.n));  // proj = abs(dot(d0, normal3d(ray_int)))
         o.n_det = 3;
         o.status |= BMO_NODE_DETECTED;
-        o.lenA = g.lenA + Xc.t;
-        o.lenB = g.lenB + Xc.t;
-        o.oplC = g.oplC + Xc.t * g.c.n;
-        o.oplW = g.oplW + tw * g.w.n;
-        o.oplD = g.oplD + td * g.d.n;
+        o.lenA = a.lenA + Xc.t;
+        o.lenB = a.lenB + Xc.t;
+        o.oplC = a.oplC + Xc.t * c.n;
+        o.oplW = a.oplW + tw * rec.ray(1).n;
+        o.oplD = a.oplD + td * rec.ray(2).n;
         o.outcome = OUT_STOP;
         return;
     }
     const bool coating = ob.kind == BMO_OBJ_THIN_BS || (ob.kind == BMO_OBJ_PLATE_BS && sh0 == ob.shape[1]) || (ob.kind == BMO_OBJ_CUBE_BS && sh0 == ob.shape[2]);
     // every sub-beam interacts with the object found by the CHIEF ray (System.jl:306-309, Gaussian.jl:124-135)
     bool all_continue = true;
-    const int entering_hint = dot3(g.c.dir, Xc.n) < 0 ? 1 : 0;
+    int entering_hint = 0;
+    double n_c = 0.0, n_w = 0.0, n_d = 0.0;  // refractive index along the three rays of this segment
     BMO_NOUNROLL
     for (int r = 0; r < 3; ++r) {
-        const RayS ray = pick_ray(r, g.c, g.w, g.d);
+        const RayS ray = rec.ray(r);
+        if (r == 0) {
+            entering_hint = dot3(ray.dir, Xc.n) < 0 ? 1 : 0;
+            n_c = ray.n;
+        } else if (r == 1) {
+            n_w = ray.n;
+        } else {
+            n_d = ray.n;
+        }
         Hit X = rec.hit(r);
         X.obj = oid;
         X.shape = sh0;
-        const double opl = r == 0 ? g.oplC : (r == 1 ? g.oplW : g.oplD);
+        const double opl = r == 0 ? a.oplC : (r == 1 ? a.oplW : a.oplD);
         StepOut so;
         so.status = 0;
         so.det = o.det + 9 * r;
-        interact<BMO_BEAM_RAY>(S, ray, X, g.li, g.lambda, opl, so, NextInOut{so}, entering_hint);
+        // the next segment (or the transmitted child) of ray r goes to the record's sink inside the interaction, its reflected child right
+        // behind it: held in registers until the slot allocation, the six rays of a beamlet were what the 168-register kernel spilled
+        interact<BMO_BEAM_RAY>(S, ray, X, a.li, a.lambda, opl, so, GaussNextSink<Rec>{rec, r}, entering_hint);
         o.status |= so.status;
-        // the next segment (or the transmitted child) and the reflected child of ray r go to the record's sink at once: held in
-        // registers until the slot allocation, the six rays of a beamlet were what the 168-register kernel spilled (round 3)
-        rec.put_next(r, so.next);
         if (so.outcome == OUT_SPLIT) rec.put_refl(r, so.refl);
         if (r == 0) {
             o.hint_obj = so.hint_obj;
@@ -1765,11 +1797,11 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         const int want = coating ? OUT_SPLIT : OUT_CONTINUE;
         if (so.outcome != want) all_continue = false;
     }
-    o.oplC = g.oplC + Xc.t * g.c.n;
-    o.oplW = g.oplW + tw * g.w.n;
-    o.oplD = g.oplD + td * g.d.n;
-    o.lenA = g.lenA + Xc.t;
-    o.lenB = g.lenB + Xc.t;
+    o.oplC = a.oplC + Xc.t * n_c;
+    o.oplW = a.oplW + tw * n_w;
+    o.oplD = a.oplD + td * n_d;
+    o.lenA = a.lenA + Xc.t;
+    o.lenB = a.lenB + Xc.t;
     if (!all_continue) {
         o.outcome = OUT_STOP;
         return;
@@ -1779,6 +1811,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
         return;
     }
     // splitter: ThinBeamsplitter.jl:117-168 (+ PlateBeamsplitter.jl:230-275, CubeBeamsplitter.jl:94-121 via interact's split modes)
+    const GaussIn g = rec.load();
     const double t_total = (g.lenA + Xc.t) + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
     const double w0 = gauss_w0_at(g, t_total, g.lenB);
     o.child_w0 = w0;
@@ -1806,6 +1839,7 @@ struct GaussRecLocal {
     BMO_HD int32_t hint_obj() const { return g.hint_obj; }
     BMO_HD int32_t hint_shape() const { return g.hint_shape; }
     BMO_HD GaussIn load() const { return g; }
+    BMO_HD GaussAcc acc() const { return GaussAcc{g.lenA, g.lenB, g.oplC, g.oplW, g.oplD, g.lambda, g.l0, g.w0, g.E0, g.li}; }
 };
 template <int EXT, bool RETR = false>
 BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,

@@ -1,7 +1,7 @@
 """Resource usage (VGPRs, SGPRs, scratch, occupancy) of the step kernels: python tools/kernel_resources.py [extra hipcc flags]"""
 import os, re, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills", "-Wno-unused-result",
        "-I", os.path.join(ROOT, "include"), "-o", "/tmp/kr_lib.so", os.path.join(ROOT, "beamletoptics.jl_amd/csrc/bmo_engine.hip"),
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
