@@ -203,6 +203,7 @@ def load_engine():
     dp = C.POINTER(C.c_double)
     lib.bmo_photodetector_field.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp]
     lib.bmo_gauss_parameters.argtypes = [vp, C.c_int64, dp, C.c_int32, dp]
+    lib.bmo_result_set_gauss_prefix.argtypes = [vp, C.c_int64, C.POINTER(C.c_int32), dp, dp]
     lib.bmo_psf_intensity.argtypes = [C.c_void_p, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp, dp, dp]
     _engine = lib
     return lib

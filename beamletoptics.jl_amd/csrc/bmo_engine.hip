@@ -1488,6 +1488,8 @@ struct bmo_trace_result {
     std::vector<std::unique_ptr<DevBuf>> wave_last;  // Chunk::wl of the fused launches
     DevBuf n_root, n_parent, n_nseg, n_status, n_li, n_hitdet, n_key, n_lambda, n_hit, n_aux, order, det_data, det_node;
     DevBuf n_old;  // retrace runs only (NodeArrays::old)
+    DevBuf pre_start, pre_segs, pre_opl;  // earlier segments of continued root beamlets (bmo_result_set_gauss_prefix), empty otherwise
+    int64_t pre_roots = 0, pre_total = 0;
     // tables a later bmo_retrace of THIS solution needs, built on first use (OldSolution)
     std::mutex rt_mu;
     bool rt_built = false;

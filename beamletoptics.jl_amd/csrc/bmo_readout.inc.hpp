@@ -139,16 +139,26 @@ namespace {
 enum { PD_SEG_PLANES = 24, PD_HS = 12 };
 // per-hit scalars: 0 l_parent 1 w0 2 E0.re 3 E0.im 4 lambda 5 proj 6 opl_parent | prepared: 7 l0 8 k 9 ref_phi 10 len_total 11 unused
 
+// Earlier segments of continued root beamlets (bmo_result_set_gauss_prefix): root node nd owns rows pre_start[nd] .. pre_start[nd + 1] of the
+// prefix table; they come in front of the segments of the log.  nullptr: no beamlet has any.
+struct PdPrefix {
+    const int32_t* start;  // [n_roots + 1]
+    const double* segs;    // [24][total]
+    const double* opl;     // [n_roots]: optical path length of the parent chain
+    int64_t n_roots, total;
+    __device__ int len(int32_t nd) const { return (start && nd < n_roots) ? start[nd + 1] - start[nd] : 0; }
+};
+
 __global__ void pd_hit_nodes_kernel(const int32_t* __restrict__ det_node, int64_t first_row, int64_t n_hits, const int32_t* __restrict__ order,
                                     const int32_t* __restrict__ nseg, const double* __restrict__ aux, const double* __restrict__ lambda,
                                     const double* __restrict__ det_data, int32_t* __restrict__ hit_node, int32_t* __restrict__ hit_nseg,
-                                    int32_t* __restrict__ node_hit, double* __restrict__ hs) {
+                                    int32_t* __restrict__ node_hit, double* __restrict__ hs, PdPrefix pre) {
     const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_hits) return;
     const int64_t row = first_row + 3 * h;  // three hit rows per beamlet, row 0 = {proj, 0, ...}
     const int32_t nd = order[det_node[row]];
     hit_node[h] = nd;
-    hit_nseg[h] = nseg[nd];
+    hit_nseg[h] = nseg[nd] + pre.len(nd);
     node_hit[nd] = (int32_t)h;
     double* s = hs + h * PD_HS;
     s[0] = aux[(int64_t)nd * 4 + 0];
@@ -160,7 +170,7 @@ __global__ void pd_hit_nodes_kernel(const int32_t* __restrict__ det_node, int64_
 }
 
 __global__ void pd_gather_kernel(Chunk c, const int32_t* __restrict__ node_hit, const int32_t* __restrict__ seg_start, int64_t total_segs,
-                                 double* __restrict__ segs, double* __restrict__ hs) {
+                                 double* __restrict__ segs, double* __restrict__ hs, PdPrefix pre) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
     const int32_t nd = chunk_node(c, j);
@@ -168,10 +178,17 @@ __global__ void pd_gather_kernel(Chunk c, const int32_t* __restrict__ node_hit, 
     const int32_t h = node_hit[nd];
     if (h < 0) return;
     const int32_t k = c.i[I_K * c.cap + j];
-    const int64_t dst = (int64_t)seg_start[h] + k;
+    const int plen = pre.len(nd);
+    const int64_t dst = (int64_t)seg_start[h] + plen + k;
     for (int b = 0; b < 3; ++b)          // chief, waist, divergence: record planes 11*b + {pos 0-2, dir 3-5, n 6, t 7}
         for (int q = 0; q < 8; ++q) segs[(int64_t)(8 * b + q) * total_segs + dst] = c.d[(int64_t)(11 * b + q) * c.cap + j];
-    if (k == 0) hs[(int64_t)h * PD_HS + 6] = c.d[(int64_t)35 * c.cap + j];  // OPL of the parent chain (optical_path_length(parent))
+    if (k == 0) {
+        // OPL of the parent chain (optical_path_length(parent)); a continued beamlet's record carries the OPL up to its open ray, the
+        // parent's share of it came with the prefix
+        hs[(int64_t)h * PD_HS + 6] = plen > 0 ? pre.opl[nd] : c.d[(int64_t)35 * c.cap + j];
+        for (int i = 0; i < plen; ++i)
+            for (int q = 0; q < PD_SEG_PLANES; ++q) segs[(int64_t)q * total_segs + seg_start[h] + i] = pre.segs[(int64_t)q * pre.total + pre.start[nd] + i];
+    }
 }
 
 __global__ void pd_prepare_kernel(int64_t n_hits, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ hit_nseg, int64_t total_segs,
@@ -307,9 +324,10 @@ __global__ void pd_reduce_kernel(const double2* __restrict__ partial, int32_t n_
 // gauss_parameters(gauss, z) for one beamlet (slot 0 of the per-hit tables) at n values of z: the same gather / prepare / locate /
 // gauss_parameters_at sequence the Photodetector field runs per grid point
 __global__ void gp_pick_kernel(int64_t canon, const int32_t* __restrict__ order, const int32_t* __restrict__ nseg, const double* __restrict__ aux,
-                               const double* __restrict__ lambda, int32_t* __restrict__ hit_nseg, int32_t* __restrict__ node_hit, double* __restrict__ hs) {
+                               const double* __restrict__ lambda, int32_t* __restrict__ hit_nseg, int32_t* __restrict__ node_hit, double* __restrict__ hs,
+                               PdPrefix pre) {
     const int32_t nd = order[canon];
-    hit_nseg[0] = nseg[nd];
+    hit_nseg[0] = nseg[nd] + pre.len(nd);
     node_hit[nd] = 0;
     hs[0] = aux[(int64_t)nd * 4 + 0];
     hs[1] = aux[(int64_t)nd * 4 + 1];
@@ -336,6 +354,37 @@ __global__ void gp_eval_kernel(int32_t n, const double* __restrict__ zs, int ns,
 
 }  // namespace
 
+static PdPrefix prefix_of(const bmo_trace_result* res) {
+    PdPrefix p{nullptr, nullptr, nullptr, 0, 0};
+    if (res->pre_start.p) p = PdPrefix{(const int32_t*)res->pre_start.p, (const double*)res->pre_segs.p, (const double*)res->pre_opl.p, res->pre_roots, res->pre_total};
+    return p;
+}
+
+extern "C" int bmo_result_set_gauss_prefix(bmo_trace_result* res, int64_t n_roots, const int32_t* prefix_start, const double* prefix_segs, const double* opl_parent) {
+    if (!res || !prefix_start || !opl_parent || n_roots <= 0) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: bad argument");
+    if (res->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: not a GaussianBeamlet solution");
+    if (n_roots != res->n_roots) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: one entry per root beamlet of the solution is expected");
+    if (prefix_start[0] != 0) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: prefix_start[0] must be 0");
+    for (int64_t i = 0; i < n_roots; ++i)
+        if (prefix_start[i + 1] < prefix_start[i]) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: prefix_start must not decrease");
+    const int64_t total = prefix_start[n_roots];
+    if (total > 0 && !prefix_segs) return fail(BMO_ERR_INVALID, "bmo_result_set_gauss_prefix: prefix_segs missing");
+    HIP_TRY(hipSetDevice(res->device));
+    int rc;
+    res->pre_start.release();
+    res->pre_segs.release();
+    res->pre_opl.release();
+    if ((rc = res->pre_start.alloc((size_t)(n_roots + 1) * 4)) || (rc = res->pre_segs.alloc((size_t)std::max<int64_t>(total, 1) * PD_SEG_PLANES * 8)) ||
+        (rc = res->pre_opl.alloc((size_t)n_roots * 8)))
+        return rc;
+    HIP_TRY(hipMemcpy(res->pre_start.p, prefix_start, (size_t)(n_roots + 1) * 4, hipMemcpyHostToDevice));
+    if (total > 0) HIP_TRY(hipMemcpy(res->pre_segs.p, prefix_segs, (size_t)total * PD_SEG_PLANES * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(res->pre_opl.p, opl_parent, (size_t)n_roots * 8, hipMemcpyHostToDevice));
+    res->pre_roots = n_roots;
+    res->pre_total = total;
+    return BMO_OK;
+}
+
 extern "C" int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const double* zs, int32_t n, double* out) {
     if (!res || !zs || !out || n <= 0) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: bad argument");
     if (res->kind != BMO_BEAM_GAUSSIAN) return fail(BMO_ERR_INVALID, "bmo_gauss_parameters: not a GaussianBeamlet solution");
@@ -352,7 +401,7 @@ extern "C" int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const d
     HIP_TRY(hipMemsetAsync(hs.p, 0, PD_HS * 8, st));
     HIP_TRY(hipMemsetAsync(seg_start.p, 0, 4, st));
     hipLaunchKernelGGL(gp_pick_kernel, dim3(1), dim3(1), 0, st, node, (const int32_t*)res->order.p, (const int32_t*)res->n_nseg.p, (const double*)res->n_aux.p,
-                       (const double*)res->n_lambda.p, (int32_t*)hit_nseg.p, (int32_t*)node_hit.p, (double*)hs.p);
+                       (const double*)res->n_lambda.p, (int32_t*)hit_nseg.p, (int32_t*)node_hit.p, (double*)hs.p, prefix_of(res));
     int32_t ns = 0;
     HIP_TRY(hipMemcpyAsync(&ns, hit_nseg.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -361,7 +410,7 @@ extern "C" int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const d
     for (const Chunk& c : res->chunks)
         if (c.count > 0)
             hipLaunchKernelGGL(pd_gather_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, st, c, (const int32_t*)node_hit.p,
-                               (const int32_t*)seg_start.p, (int64_t)ns, (double*)segs.p, (double*)hs.p);
+                               (const int32_t*)seg_start.p, (int64_t)ns, (double*)segs.p, (double*)hs.p, prefix_of(res));
     hipLaunchKernelGGL(pd_prepare_kernel, dim3(1), dim3(256), 0, st, (int64_t)1, (const int32_t*)seg_start.p, (const int32_t*)hit_nseg.p, (int64_t)ns,
                        (const double*)segs.p, (double*)cum.p, (double*)hs.p);
     HIP_TRY(hipMemcpyAsync(d_z.p, zs, (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -400,7 +449,7 @@ extern "C" int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, 
     const unsigned hb = (unsigned)((H + 255) / 256);
     hipLaunchKernelGGL(pd_hit_nodes_kernel, dim3(hb), dim3(256), 0, st, (const int32_t*)res->det_node.p, res->det_offset[detector], H,
                        (const int32_t*)res->order.p, (const int32_t*)res->n_nseg.p, (const double*)res->n_aux.p, (const double*)res->n_lambda.p,
-                       (const double*)res->det_data.p, (int32_t*)hit_node.p, (int32_t*)hit_nseg.p, (int32_t*)node_hit.p, (double*)hs.p);
+                       (const double*)res->det_data.p, (int32_t*)hit_node.p, (int32_t*)hit_nseg.p, (int32_t*)node_hit.p, (double*)hs.p, prefix_of(res));
     size_t tmp_bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)hit_nseg.p, (int32_t*)seg_start.p, (int)H, st));
     if ((rc = tmp.alloc(tmp_bytes))) return rc;
@@ -424,7 +473,7 @@ extern "C" int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, 
     for (const Chunk& c : res->chunks)
         if (c.count > 0)
             hipLaunchKernelGGL(pd_gather_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, st, c, (const int32_t*)node_hit.p,
-                               (const int32_t*)seg_start.p, total_segs, (double*)segs.p, (double*)hs.p);
+                               (const int32_t*)seg_start.p, total_segs, (double*)segs.p, (double*)hs.p, prefix_of(res));
     hipLaunchKernelGGL(pd_prepare_kernel, dim3(hb), dim3(256), 0, st, H, (const int32_t*)seg_start.p, (const int32_t*)hit_nseg.p, total_segs,
                        (const double*)segs.p, (double*)cum.p, (double*)hs.p);
     HIP_TRY(hipMemcpyAsync(d_xs.p, xs, (size_t)nx * 8, hipMemcpyHostToDevice, st));

@@ -389,6 +389,15 @@ class EngineSolution:
         abi.check(self.lib, self.lib.bmo_gauss_parameters(self.handle, int(node), z.ctypes.data_as(dp), len(z), out.ctypes.data_as(dp)), "bmo_gauss_parameters")
         return out
 
+    def set_gauss_prefix(self, prefix_start, prefix_segs, opl_parent):
+        """bmo_result_set_gauss_prefix: the earlier segments of continued beamlets ([n_roots + 1] starts, [24, total] planes, [n_roots] parent OPL)."""
+        st = np.ascontiguousarray(prefix_start, dtype=np.int32)
+        sg = np.ascontiguousarray(prefix_segs, dtype=np.float64)
+        op = np.ascontiguousarray(opl_parent, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        abi.check(self.lib, self.lib.bmo_result_set_gauss_prefix(self.handle, len(op), st.ctypes.data_as(C.POINTER(C.c_int32)), sg.ctypes.data_as(dp),
+                                                                 op.ctypes.data_as(dp)), "bmo_result_set_gauss_prefix")
+
     def photodetector_field(self, slot, position, orientation, xs, ys, field):
         """bmo_photodetector_field: adds the field of the beamlets recorded on detector `slot` to `field[i, j]` (in place)."""
         dp = C.POINTER(C.c_double)
@@ -489,11 +498,6 @@ def _trace_open_leaves(system, roots, r_max, device):
         by_left.setdefault(r_max - len(b.rays) + 1, []).append(b)
     for left, group in sorted(by_left.items()):
         gaussian = group[0].kind == bm.BEAM_GAUSSIAN
-        if gaussian and any(isinstance(o, cp.Photodetector) for o in system.objects()):
-            # the field of a beamlet on a Photodetector is evaluated on the device from ALL of its segments (bmo_photodetector_field); the
-            # continuation holds only those from the open ray on
-            raise NotImplementedError("solve_system(retrace=False) on solved GaussianBeamlets in a system with a Photodetector: retrace them "
-                                      "(retrace=True) or release() and solve afresh")
         heads = []
         for b in group:
             if gaussian:
@@ -530,6 +534,21 @@ def _trace_open_leaves(system, roots, r_max, device):
             bundle = bm.RayBundle(bundle.kind, np.vstack([bundle.planes, acc]))
         scene = CompiledScene(system, bundle.lambdas)
         res, sol = _engine_solve(scene, bundle, left, None, device)
+        if gaussian and any(isinstance(o, cp.Photodetector) for o in system.objects()):
+            # the field of a beamlet on a Photodetector is a function of ALL its rays (point_on_beam, length, optical_path_length:
+            # Beam.jl:125-205); the continuation holds only those from the open ray on, the ones in front of it go along as a prefix
+            starts, cols, opl_par = [0], [], []
+            for b in group:
+                for k in range(len(b.chief.rays) - 1):
+                    col = []
+                    for part in (b.chief, b.waist, b.divergence):
+                        r = part.rays[k]
+                        col += [r.pos[0], r.pos[1], r.pos[2], r.dir[0], r.dir[1], r.dir[2], r.n, r.intersection.t]
+                    cols.append(col)
+                starts.append(len(cols))
+                opl_par.append(0.0 if b.chief.parent is None else b.chief.parent.optical_path_length())
+            segs = np.asarray(cols, dtype=np.float64).T if cols else np.zeros((24, 0))
+            sol.set_gauss_prefix(starts, segs, opl_par)
         # optical path length of each beam (parents included) up to the start of its open ray: what PSF records of the continuation add
         opl0 = []
         for b in group:

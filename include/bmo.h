@@ -412,6 +412,18 @@ int bmo_photodetector_field(bmo_trace_result* res, int32_t detector, const doubl
  * known-answer tests (test/runtests.jl:1811-1932) can be run against the device arithmetic itself.                         */
 int bmo_gauss_parameters(bmo_trace_result* res, int64_t node, const double* zs, int32_t n, double* out);
 
+/* Earlier segments of CONTINUED GaussianBeamlets — solve_system!(system, beams; retrace = false) on beamlets solved before traces their
+ * open last rays on (src/System.jl:449-458, solve_leaf! :470-475); `res` is the solution of such a continuation (root beamlet i = the
+ * i-th continued beamlet from its open ray on, bmo.h "31 planes").  gauss_parameters and the Photodetector field of a beamlet are
+ * functions of ALL its rays (point_on_beam, length, optical_path_length: src/Beam.jl:125-205), so the rays in front of the open one are
+ * handed over here before bmo_photodetector_field / bmo_gauss_parameters are called on `res`:
+ *   prefix_start[n_roots + 1] : exclusive scan of the number of earlier segments per root beamlet (0 for a beamlet without any);
+ *   prefix_segs[24][total]    : plane 8 b + q of segment s at [(8 b + q) * total + s]; b = chief, waist, divergence;
+ *                               q = pos 0-2, dir 3-5, refractive index 6, length t 7;   total = prefix_start[n_roots];
+ *   opl_parent[n_roots]       : optical_path_length(parent(chief beam)), 0 without a parent.
+ * The tables are copied to the device and replace an earlier prefix of `res`.  n_roots must be the root count of `res`.        */
+int bmo_result_set_gauss_prefix(bmo_trace_result* res, int64_t n_roots, const int32_t* prefix_start, const double* prefix_segs, const double* opl_parent);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,12 +356,43 @@ def test_solve_again_without_retrace_continues_open_gaussian_beamlets():
     assert deep > 0  # the second splitter was reached in the continuation and sized its children from the seeded lengths
     psf_a, psf_b = sys1.objects()[-1], sys_full.objects()[-1]
     assert len(psf_a.data) == len(psf_b.data) > 0 and np.array_equal(np.asarray(psf_a.data), np.asarray(psf_b.data))
-    # a system with a Photodetector is refused (its field needs every segment of the beamlet on the device)
-    pd = bmo.Photodetector(5 * mm, 16)
-    bmo.translate3d(pd, [0, 300 * mm, 0])
-    g = beamlets()[0]
-    bmo.solve_system(sys0, g)
-    with pytest.raises(NotImplementedError):
-        bmo.solve_system(bmo.System(sys0.objects() + [pd]), g, retrace=False)
-    for x in again + fresh + [g]:
+    for x in again + fresh:
+        bmo.release(x)
+
+
+@pytest.mark.gpu
+def test_continued_beamlets_reach_a_photodetector():
+    """solve_system!(...; retrace = false) on solved GaussianBeamlets whose continuation ends on a Photodetector (Photodetector.jl:69-107):
+    the field is a function of every ray of the beamlet (point_on_beam / length / optical_path_length, Beam.jl:125-205), the rays in front of
+    the open one go to the device as a prefix (bmo_result_set_gauss_prefix).  Same field as a solve that never stopped."""
+    mm = 1e-3
+
+    def build():
+        l1 = bmo.SphericalLens(50 * mm, -50 * mm, 5 * mm, 20 * mm, 1.5)
+        bmo.translate3d(l1, [0, 20 * mm, 0])
+        l2 = bmo.SphericalLens(80 * mm, -80 * mm, 4 * mm, 20 * mm, 1.6)
+        bmo.translate3d(l2, [0, 60 * mm, 0])
+        pd = bmo.Photodetector(4 * mm, 24)
+        bmo.translate3d(pd, [0, 140 * mm, 0])
+        return bmo.System([l1, l2, pd]), pd
+
+    def beamlets():
+        return [bmo.GaussianBeamlet([dx * mm, 0, 0.1 * dx * mm], [0.01 * dx, 1.0, 0.0], 1064e-9, 0.4 * mm, support=[1, 0, 0]) for dx in (-1.0, 0.0, 0.7, 1.3)]
+
+    sys_a, pd_a = build()
+    stopped = beamlets()
+    for g in stopped:
+        bmo.solve_system(sys_a, g, r_max=3)  # stops inside the second lens: three rays, the last one open
+        assert len(g.chief.rays) == 3 and g.chief.rays[-1].intersection is None
+    assert not np.any(pd_a.field)
+    for g in stopped:
+        assert bmo.solve_system(sys_a, g, r_max=20, retrace=False) is None
+        assert g.chief.rays[-1].intersection is not None and len(g.chief.rays) == 5
+    sys_b, pd_b = build()
+    full = beamlets()
+    for g in full:
+        bmo.solve_system(sys_b, g, r_max=20)
+    assert np.any(pd_b.field)
+    np.testing.assert_allclose(pd_a.field, pd_b.field, rtol=1e-12, atol=1e-12 * np.abs(pd_b.field).max())
+    for x in stopped + full:
         bmo.release(x)
