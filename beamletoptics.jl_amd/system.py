@@ -463,9 +463,11 @@ def _prepare(system, beams):
     return roots, bundle, scene, prev
 
 
-def _apply(scene, res, sol, roots, hit_fix=None):
+def _apply(scene, res, sol, roots, hit_fix=None, defer=False):
     """Fill the beam objects from a TraceResult and append this solve's detector records (detectors are not reset, like the reference:
-    Spotdetector.jl / PSFDetector.jl "Reset behavior").  `hit_fix(slot, hits)` may adjust the rows before they are appended."""
+    Spotdetector.jl / PSFDetector.jl "Reset behavior").  `hit_fix(slot, hits)` may adjust the rows before they are appended.  With `defer`
+    the Spot / PSF rows are not appended but left on the beam that made them (`_pending_hits`), for a caller that merges several solves into
+    the reference's order (_trace_open_leaves)."""
     nodes = _fill_beams(scene, res, roots)
     for i, b in enumerate(roots):
         b._solution, b._sol_index = sol, i
@@ -473,6 +475,11 @@ def _apply(scene, res, sol, roots, hit_fix=None):
         hits = res.detector_hits(slot)
         if hit_fix is not None:
             hits = hit_fix(slot, hits)
+        if defer and det.kind != cp.O_PHOTODETECTOR:
+            rows = hits[:, 0:2] if det.kind == cp.O_SPOT else hits
+            for nd, row in zip(res.detector_nodes(slot), rows):
+                nodes[int(nd)].__dict__.setdefault("_pending_hits", []).append((det, row))
+            continue
         if det.kind == cp.O_SPOT:
             det.data = np.concatenate([det.data, hits[:, 0:2]], axis=0)
         elif det.kind == cp.O_PHOTODETECTOR:
@@ -486,13 +493,35 @@ def _apply(scene, res, sol, roots, hit_fix=None):
 def _trace_open_leaves(system, roots, r_max, device):
     """solve_system!(...; retrace = false) on beams that were solved before (System.jl:449-458, solve_leaf! :470-475): nothing is re-walked;
     every beam of the trees whose LAST ray has no intersection is traced on from that ray (without a hint, up to r_max rays in the beam),
-    everything else stays as it is.  The open last rays are traced as one fresh batch per distinct remaining length and spliced back."""
+    everything else stays as it is.  The open last rays are traced as one fresh batch per distinct remaining length and spliced back.
+    A batch applies ONE ray limit to all its beams, the remaining length of the beams it continues, while the reference gives every child
+    born in the continuation the full r_max: children that ran into the batch's limit are open beams themselves and are continued by the next
+    pass.  Detector rows are appended at the end, in the order the reference's loop makes them: root by root, breadth-first."""
     open_beams, queue = [], list(roots)
     while queue:  # BFS like solve_system!
         b = queue.pop(0)
         queue.extend(b.children)
         if b.rays[-1].intersection is None and len(b.rays) < r_max:
             open_beams.append(b)
+    while open_beams:
+        open_beams = _continue_open_beams(system, open_beams, r_max, device)
+    queue = list(roots)
+    while queue:
+        b = queue.pop(0)
+        queue.extend(b.children)
+        for det, row in b.__dict__.pop("_pending_hits", []):
+            det.data = np.concatenate([det.data, np.asarray(row)[None, :]], axis=0)
+    for b in roots:  # the resident solution no longer describes these beams: the next solve traces them afresh
+        sol = getattr(b, "_solution", None)
+        if sol is not None:
+            sol.free()
+        b._solution = None
+    return None
+
+
+def _continue_open_beams(system, open_beams, r_max, device):
+    """One pass of _trace_open_leaves; returns the beams born in it that ran into the pass's ray limit below r_max."""
+    again = []
     by_left = {}
     for b in open_beams:
         by_left.setdefault(r_max - len(b.rays) + 1, []).append(b)
@@ -565,7 +594,7 @@ def _trace_open_leaves(system, roots, r_max, device):
             hits[:, 6] += np.asarray(opl0)[root_of_hit]
             return hits
 
-        _apply(scene, res, sol, heads, hit_fix)
+        nodes = _apply(scene, res, sol, heads, hit_fix, defer=True)
         sol.free()
         for b, h in zip(group, heads):
             if gaussian:
@@ -579,12 +608,12 @@ def _trace_open_leaves(system, roots, r_max, device):
             for c in h.children:
                 c.parent = b
             b.children = h.children
-    for b in roots:  # the resident solution no longer describes these beams: the next solve traces them afresh
-        sol = getattr(b, "_solution", None)
-        if sol is not None:
-            sol.free()
-        b._solution = None
-    return None
+            pend = h.__dict__.pop("_pending_hits", None)
+            if pend:
+                b.__dict__.setdefault("_pending_hits", []).extend(pend)
+        if left < r_max:
+            again += [nd for nd in nodes[len(group):] if (nd.status & abi.NODE_RMAX) and nd.rays[-1].intersection is None and len(nd.rays) < r_max]
+    return again
 
 
 def solve_system(system, beams, r_max=100, retrace=True, device=0):

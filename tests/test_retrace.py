@@ -396,3 +396,63 @@ def test_continued_beamlets_reach_a_photodetector():
     np.testing.assert_allclose(pd_a.field, pd_b.field, rtol=1e-12, atol=1e-12 * np.abs(pd_b.field).max())
     for x in stopped + full:
         bmo.release(x)
+
+
+@pytest.mark.gpu
+def test_children_born_in_a_continuation_get_the_full_r_max():
+    """solve_system!(...; retrace = false): the continued beam has r_max - length rays left, the children a splitter makes in the continuation
+    have all of r_max (every Beam counts its own rays, System.jl:118-154) — and detector rows come in the reference's order, root by root."""
+    mm = 1e-3
+
+    def build(stage):
+        l1 = bmo.SphericalLens(60 * mm, -60 * mm, 4 * mm, 20 * mm, 1.5)
+        bmo.translate3d(l1, [0, 20 * mm, 0])
+        objs = [l1]
+        if stage >= 1:
+            bs = bmo.ThinBeamsplitter(30 * mm)
+            bmo.xrotate3d(bs, math.radians(45))
+            bmo.translate3d(bs, [0, 60 * mm, 0])
+            l2 = bmo.SphericalLens(70 * mm, -70 * mm, 4 * mm, 20 * mm, 1.5)
+            bmo.translate3d(l2, [0, 90 * mm, 0])
+            l3 = bmo.SphericalLens(90 * mm, -90 * mm, 3 * mm, 20 * mm, 1.6)
+            bmo.translate3d(l3, [0, 110 * mm, 0])
+            sd = bmo.Spotdetector(20 * mm)
+            bmo.translate3d(sd, [0, 150 * mm, 0])
+            objs += [bs, l2, l3, sd]
+        return bmo.System(objs)
+
+    def beams():
+        return [bmo.Beam(bmo.Ray([dx * mm, 0, 0.3 * dx * mm], [0, 1.0, 0], 1e-6)) for dx in (0.0, 1.0, -2.0, 3.0)]
+
+    r_max = 6
+    sys_full = build(1)
+    fresh = beams()
+    for b in fresh:
+        bmo.solve_system(sys_full, b, r_max=r_max)
+    sd_full = sys_full.objects()[-1]
+    assert len(sd_full.data) == len(fresh)  # the transmitted child takes 5 rays to the detector: more than the 4 the continued beam has left
+    again = beams()
+    sys0 = build(0)
+    for b in again:
+        bmo.solve_system(sys0, b, r_max=r_max)
+        assert len(b.rays) == 3 and b.rays[-1].intersection is None
+    sys1 = build(1)
+    for b in again:
+        assert bmo.solve_system(sys1, b, r_max=r_max, retrace=False) is None
+    sd1 = sys1.objects()[-1]
+    assert np.array_equal(np.asarray(sd1.data), np.asarray(sd_full.data))
+
+    def same(a, b):
+        assert len(a.rays) == len(b.rays) and len(a.children) == len(b.children)
+        for ra, rb in zip(a.rays, b.rays):
+            assert np.array_equal(ra.pos, rb.pos) and np.array_equal(ra.dir, rb.dir)
+            assert (ra.intersection is None) == (rb.intersection is None)
+            if ra.intersection is not None:
+                assert ra.intersection.t == rb.intersection.t
+        for ca, cb in zip(a.children, b.children):
+            same(ca, cb)
+
+    for a, b in zip(again, fresh):
+        same(a, b)
+    for x in again + fresh:
+        bmo.release(x)
