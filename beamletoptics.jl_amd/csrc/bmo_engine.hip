@@ -1,19 +1,22 @@
 // bmo_engine.hip — MI355X (gfx950) trace engine behind the C ABI of include/bmo.h.
 //
-// Execution model: bounce-synchronous wavefront tracing.
-//   * One launch of step_kernel advances every ACTIVE beam node by up to 32 bounces
+// Execution model: wavefront tracing, bounce levels fused per wave.
+//   * One launch of step_kernel / step_kernel_gauss advances every ACTIVE beam node by up to 32 (31) bounces
 //     (tracing_step! + interact3d, System.jl:133-152).  Lane j works on record j of the
 //     current step chunk; the segment log IS the sequence of step chunks (SoA planes), so a
 //     bounce reads the 64 B it needs (pos, dir, n, hint) and writes intersection + next
 //     segment once — SURVEY.md §8d's 184 B/bounce.  Inside a launch a beam that goes on writes
 //     its next record in place (same slot of the next in-place chunk); every wave runs its
-//     own level loop and notes how far it got (Chunk::wl).
-//   * The scene tables (objects, shapes, triangles, n(lambda)) are staged into LDS by every
-//     workgroup; rays stay in HBM as structure-of-arrays planes (coalesced 8 B/lane loads).
-//     Shapes carry a class id: the lanes of a wave visit shapes of one class together, so the
-//     leaf switches branch on scalar compares (bmo_lane.hpp "wave-uniform control flow").
-//   * Survivors and beam-splitter children are compacted into the next chunk with a wave
-//     ballot + prefix popcount and ONE atomic per counter per workgroup (child node ids likewise).
+//     own level loop and notes how far it got (Chunk::wl).  A beam splitter met in the loop keeps
+//     its transmitted child in the lane and pushes the reflected one to the next launch's chunk
+//     (one reservation per wave); launches over few records spread them thinly over the waves.
+//   * The scene tables (objects, shapes, triangles, n(lambda), candidate table) stay in global memory
+//     and are read with SCALAR loads through constant-address-space pointers: the wave works on one
+//     shape at a time, lanes that disagree on it take turns (bmo_lane.hpp "scalar scene access").
+//     Rays stay in HBM as structure-of-arrays planes (coalesced 8 B/lane loads); LDS holds two
+//     per-lane columns only (the union children's Lipschitz memory, the lane memory of tracing_step).
+//   * Survivors of a launch's last fused level are compacted into the next chunk with a wave
+//     ballot + prefix popcount and ONE atomic per workgroup.
 //   * After the last step, nodes are put in the reference's order (bundle order x BFS order):
 //     heap-index bitmaps per root for trees of up to 5 levels, a radix sort on (root, depth,
 //     path) keys up to 26, level-by-level ranking beyond; detector hits are compacted in that
@@ -1798,8 +1801,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     int64_t n_nodes = n;
     double kernel_ms = 0;
     int steps = 0;
-    // bounces per launch (Beam kernels): fewer launches, host round trips and scene stagings; holes instead of compaction inside a
-    // launch.  BMO_FUSE=1 restores one launch per bounce level.
+    // bounces per launch: fewer launches and host round trips; holes instead of compaction inside a launch.  BMO_FUSE=1 (BMO_FUSE_GAUSS=1)
+    // restores one launch per bounce level.
     // measured on C1-C5: 8 levels per launch beat 4 by 1-4 % at 10^6 beams and by 8-10 % below 10^5; with per-wave loops 16 beat 8 by
     // another 1-3 %, and 32 beat 16 by 1-2.5 % (config C2 reaches its splitter, level 17, in the first launch: 2 launches instead of 3).
     // The GaussianBeamlet kernels need one in-place chunk more than they fuse levels (step_kernel_gauss): one level fewer.
@@ -1808,7 +1811,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (const char* e = getenv(GAUSS ? "BMO_FUSE_GAUSS" : "BMO_FUSE")) fuse_max = std::max(1, std::min(fuse_max, atoi(e)));
     DevBuf gstage;
     int64_t gstage_cap = 0;
-    double keep_ratio = 1.0;  // share of the previous launch's beams that went on: holes are only cheap while few beams end
+    double keep_ratio = 1.0;  // share of the previous launch's beams that went on (the fuse-count rule of round 2: launches above BMO_INWAVE_MAX only)
     while (cur.count > 0) {
         const int64_t m = cur.count;
         static const double keep_hi = getenv("BMO_KEEP_HI") ? atof(getenv("BMO_KEEP_HI")) : 0.9, keep_lo = getenv("BMO_KEEP_LO") ? atof(getenv("BMO_KEEP_LO")) : 0.6;

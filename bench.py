@@ -155,15 +155,16 @@ class Case:
 
 
 def measured_traffic(name, n, r_max):
-    """HBM bytes per launch of the workload's step kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
-    this timed process): FETCH_SIZE x 2 + WRITE_SIZE, separate passes (MI355X_MICROARCH.md "HBM"), same command, default size only."""
+    """HBM bytes per SOLVE of the workload's step kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    this timed process): FETCH_SIZE x 2 + WRITE_SIZE, separate passes (MI355X_MICROARCH.md "HBM"), same command, default size only.
+    roofline_of divides by the launches per solve of THIS run, like the algorithmic bytes."""
     tp = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if not os.path.exists(tp) or n != DEFAULT_RAYS.get(name) or r_max != 100:
         return None, None
     tj = json.load(open(tp)).get(name)
     if not tj:
         return None, None
-    return (2 * tj["fetch_size_bytes"] + tj["write_size_bytes"]) / tj["launches"], tj["source"]
+    return 2 * tj["fetch_size_bytes"] + tj["write_size_bytes"], tj["source"]
 
 
 def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=None):
@@ -171,7 +172,8 @@ def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=N
     achieved = alg * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     per_step = max(launches // max(steps, 1), 1)
     return {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic / per_step if traffic is not None else None,
         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
         "kernel": KERNEL_NAME[case.kind], "launches_per_step": per_step, "avg_launch_ms": kernel_ms / max(launches, 1),
         "algorithmic_bytes_per_launch": alg / per_step,

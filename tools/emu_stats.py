@@ -1,4 +1,4 @@
-"""SDF evaluations per record and bounce level on C2 (or its vignetted bundle: `emu_stats.py N c2v`), counted by the host emulator built
+"""SDF evaluations per record and bounce level on C2 (or its vignetted bundle: `emu_stats.py N c2v`, SURVEY's literal bundle: `emu_stats.py N c2s`), counted by the host emulator built
 with -DBMO_EMU_STATS (CPU only)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -13,5 +13,6 @@ emu.bmo_emu_free.argtypes = [C.c_void_p]
 parity._emu = emu
 system, _ = scenes.c2_scene()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-b = scenes.c2_vignetted_bundle(n) if len(sys.argv) > 2 and sys.argv[2] == "c2v" else scenes.c2_bundle(n)
+which = sys.argv[2] if len(sys.argv) > 2 else "c2"
+b = {"c2v": scenes.c2_vignetted_bundle, "c2s": scenes.c2_survey_bundle}.get(which, scenes.c2_bundle)(n)
 parity.emu_trace(bmo.CompiledScene(system, b.lambdas), b, 20)
