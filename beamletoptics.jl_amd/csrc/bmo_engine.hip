@@ -183,6 +183,10 @@ struct NodeArrays {
     int64_t cap;
     int32_t hit_sub;  // detector records per node: 1 (Ray / PolarizedRay), 3 (GaussianBeamlet: chief, waist, divergence)
     int32_t* old;     // retrace only: node of the previous solution this beam re-walks, -1 once it traces freshly
+    // [roots] the heap indices (tree_bits below: 2^depth - 1 + path) of the nodes of every root's tree, one bit each, for trees of up to 5
+    // levels: set where the nodes are made (init_roots_kernel, the step kernels' make_children) so that the final ordering needs no pass
+    // over the nodes to collect them; nullptr when the scene has no beam splitter
+    unsigned long long* tbits;
 };
 
 // Tables of the previous solution a retrace re-walks (System.jl:188-255), indexed by ITS node ids; all device pointers.
@@ -535,6 +539,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
             const int32_t root = P.nodes.root[node];
             atomicMax(&P.ctr->max_depth, depth + 1ull);
+            if (P.nodes.tbits && depth < 5) atomicOr(&P.nodes.tbits[root], 3ull << ((2ull << depth) - 1ull + (path << 1)));  // both children's heap indices
             for (int w = 0; w < 2; ++w) {
                 const int64_t c = cn + w;
                 P.nodes.root[c] = root;
@@ -904,6 +909,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
                     const unsigned long long depth = pkey >> 32, path = pkey & 0xFFFFFFFFull;
                     const int32_t root = P.nodes.root[node];
                     atomicMax(&P.ctr->max_depth, depth + 1ull);
+                    if (P.nodes.tbits && depth < 5) atomicOr(&P.nodes.tbits[root], 3ull << ((2ull << depth) - 1ull + (path << 1)));
                     for (int w = 0; w < 2; ++w) {
                         const int64_t c = cn + w;
                         P.nodes.root[c] = root;
@@ -1035,6 +1041,7 @@ __global__ void init_roots_kernel(const double* __restrict__ planes, const doubl
     nodes.lambda[j] = planes[(KIND == BMO_BEAM_GAUSSIAN ? 18 : 6) * n + j];
     nodes.hit_det[j] = -1;
     nodes.key[j] = 0;
+    if (nodes.tbits) nodes.tbits[j] = 1ull;  // the root itself: heap index 0
 }
 // the batch's planes in slot order: out[p][s] = in[p][perm[s]]
 __global__ void bin_planes_kernel(const double* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int n_planes, double* __restrict__ out) {
@@ -1639,6 +1646,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         return BMO_OK;
     };
     if ((rc = alloc_nodes(node_cap))) return rc;
+    DevBuf tbits_buf;  // NodeArrays::tbits (allocated below when the scene has a splitter)
     auto node_arrays = [&]() {
         NodeArrays a;
         a.root = (int32_t*)R->n_root.p;
@@ -1654,6 +1662,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         a.cap = node_cap;
         a.hit_sub = nsub;
         a.old = (int32_t*)R->n_old.p;
+        a.tbits = (unsigned long long*)tbits_buf.p;
         return a;
     };
     auto grow_nodes = [&](int64_t need) -> int {
@@ -1755,6 +1764,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         old_tab.rec_obj = (const int32_t*)prev->rt_rec_obj.p;
         old_tab.aux = (const double*)prev->n_aux.p;
     }
+    if (has_split && n > 0 && (rc = tbits_buf.alloc((size_t)n * 8))) return rc;
     if (n > 0) {
         // a retrace re-walks the stored first ray whatever r_max says (System.jl:197); root j re-walks old node j
         hipLaunchKernelGGL((init_roots_kernel<KIND>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const double*)batch->planes.p,
@@ -2031,9 +2041,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         DevBuf *bits = temp((size_t)n * 8), *cnt = temp((size_t)n * 4), *base = temp((size_t)n * 4);
         if (!bits || !cnt || !base) return BMO_ERR_OOM;
         const unsigned rb = (unsigned)((n + 255) / 256);
-        HIP_TRY(hipMemsetAsync(bits->p, 0, (size_t)n * 8, stream));
-        hipLaunchKernelGGL(tree_bits_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes,
-                           (unsigned long long*)bits->p);
+        if (tbits_buf.p) {  // collected while the nodes were made
+            bits = &tbits_buf;
+        } else {
+            HIP_TRY(hipMemsetAsync(bits->p, 0, (size_t)n * 8, stream));
+            hipLaunchKernelGGL(tree_bits_kernel, dim3(nb), dim3(256), 0, stream, (const int32_t*)R->n_root.p, (const unsigned long long*)R->n_key.p, n_nodes,
+                               (unsigned long long*)bits->p);
+        }
         hipLaunchKernelGGL(tree_count_kernel, dim3(rb), dim3(256), 0, stream, (const unsigned long long*)bits->p, n, (int32_t*)cnt->p);
         size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)cnt->p, (int32_t*)base->p, (int)n, stream));
