@@ -1195,10 +1195,19 @@ __global__ void hit_gather_kernel(const int32_t* __restrict__ order, const int32
     }
     __syncthreads();
     const int width = 9 * nsub;
+    // element t = e * width + k of the workgroup's 256 records; t advances by 256 per turn: (e, k) by (256 / width, 256 % width) with a
+    // carry, no division per element
+    const int de = 256 / width, dk = 256 % width;
+    int e = (int)threadIdx.x / width, k = (int)threadIdx.x % width;
     for (int t = threadIdx.x; t < 256 * width; t += 256) {
-        const int e = t / width, k = t - e * width;
         const int32_t pos = s_pos[e];
         if (pos >= 0) out[(int64_t)pos * 9 + k] = hit[(int64_t)s_nd[e] * width + k];
+        e += de;
+        k += dk;
+        if (k >= width) {
+            k -= width;
+            e += 1;
+        }
     }
 }
 
