@@ -833,12 +833,11 @@ struct LaneMem {
 // the `nothing` decisions of cull_entry without its square root: the line misses the (inflated) bounding sphere, or the origin is
 // outside it and receding
 BMO_HD bool cull_miss(double cx, double cy, double cz, double R, const d3& pos, const d3& dir) {
-    if (!(R >= 0.0)) return false;
     const d3 oc{cx - pos.x, cy - pos.y, cz - pos.z};
     const double dd = dot3(dir, dir), b = dot3(oc, dir), cc = dot3(oc, oc), R2 = R * R;
-    if (!(cc > R2)) return false;
-    if (b < 0.0) return true;
-    return b * b - dd * (cc - R2) < 0.0;
+    // (`&` / `|` on purpose: one straight line of compares instead of an execution-mask branch per early exit — the candidate collection of
+    //  tracing_step runs this for every table entry and level)
+    return (R >= 0.0) & (cc > R2) & ((b < 0.0) | (b * b - dd * (cc - R2) < 0.0));
 }
 
 // tracing_step! (System.jl:100-110) = trace_one (:74-85) falling back to trace_all (:57-72), with intersect3d of objects
@@ -1108,7 +1107,7 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                                 const int i = i0 + u < c1 ? i0 + u : c1 - 1;
                                 const BMO_KONST Cand& cd = S.cands[c0 + i];
                                 const int32_t co = cd.obj, cs = cd.sid;
-                                want[u] = i0 + u < c1 && collect && co >= o_lo && co < o_hi && co != skip_obj && cs != tested_shape &&
+                                want[u] = (i0 + u < c1) & collect & (co >= o_lo) & (co < o_hi) & (co != skip_obj) & (cs != tested_shape) &
                                           !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
                             }
                             for (int u = 0; u < 4; ++u) {
