@@ -2373,7 +2373,7 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     off = al(off + 8 * (size_t)std::max(1, d->n_coefs));
     h.off_cands = (uint32_t)off;
     h.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, nullptr);
-    off = al(off + sizeof(Cand) * (size_t)std::max(1, h.n_cands));
+    off = al(off + sizeof(Cand) * (size_t)(std::max(1, h.n_cands) + 3));  // (+ 3 zero entries: the collection of tracing_step reads four per trip)
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);

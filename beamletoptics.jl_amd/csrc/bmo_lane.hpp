@@ -1103,12 +1103,13 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                         BMO_NOUNROLL
                         for (int i0 = 0; i0 < c1; i0 += 4) {
                             bool want[4];
+                            const BMO_KONST Cand* cp = S.cands + (c0 + i0);  // (the table is padded: entries behind the last one are zeros)
                             for (int u = 0; u < 4; ++u) {
-                                const int i = i0 + u < c1 ? i0 + u : c1 - 1;
-                                const BMO_KONST Cand& cd = S.cands[c0 + i];
+                                const BMO_KONST Cand& cd = cp[u];
                                 const int32_t co = cd.obj, cs = cd.sid;
-                                want[u] = (i0 + u < c1) & collect & (co >= o_lo) & (co < o_hi) & (co != skip_obj) & (cs != tested_shape) &
-                                          !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
+                                // (only the retrace probe narrows the object range or excludes an object)
+                                const bool in_range = RETR ? ((co >= o_lo) & (co < o_hi) & (co != skip_obj)) : true;
+                                want[u] = (i0 + u < c1) & collect & in_range & (cs != tested_shape) & !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
                             }
                             for (int u = 0; u < 4; ++u) {
                                 mask |= (unsigned long long)want[u] << (i0 + u);

@@ -78,7 +78,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
-    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)));
+    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)) + 3);  // (+ 3: read four per trip)
     S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
     S.cands = cands.data();
     S.eps_srf = d->eps_srf;
@@ -360,7 +360,7 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
     S.coefs = d->coefs;
     S.n_objects = d->n_objects;
     S.n_lambda = d->n_lambda;
-    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)));
+    std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)) + 3);  // (+ 3: read four per trip)
     S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
     S.cands = cands.data();
     S.eps_srf = d->eps_srf;
