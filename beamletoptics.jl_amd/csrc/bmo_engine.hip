@@ -382,6 +382,10 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     };
 
     int b = 0;  // fused bounce index: records of bounce b live in C = (b == 0 ? P.cur : P.inner[b - 1]) at slot j
+    // What a lane that goes on in place takes to the top of the next level: the header of the record it has just written (registers — nothing
+    // else is live there) and, in the lane memory, the ray's position and direction where interact's sink left them.  Reading the record
+    // back from the chunk cost eleven loads from L2 per level, each at the head of the level's dependency chain.
+    int32_t c_node = -1, c_k = 0, c_ho = -1, c_hs = -1, c_fl = 0;
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk_last = wall_clock64();  // time before / in / after tracing_step, summed over the levels
 #endif
@@ -398,22 +402,36 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         double x_t = kinf();
         bool traced = false;  // the lane ran a tracing step at this level (its record is not a pushed-but-never-traced one)
         const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
+        const int32_t t_node = c_node, t_k = c_k, t_ho = c_ho, t_hs = c_hs, t_fl = c_fl;
+        c_node = c_k = c_ho = c_hs = c_fl = 0;  // (dead from here to the next in-place write, in every lane: no register across the marches)
         if (alive) {
             const int64_t cap = C.cap;
             const double* D = C.d;
             const int32_t* I = C.i;
-            const int32_t flags = I[I_FLAGS * cap + j];
-            int32_t ho = I[I_HOBJ * cap + j], hs = I[I_HSHAPE * cap + j];
-            node = I[I_NODE * cap + j];
-            k = I[I_K * cap + j];
+            int32_t flags = t_fl, ho = t_ho, hs = t_hs;
+            node = t_node;
+            k = t_k;
+            if (b == 0) {  // (wave-uniform) the launch's input chunk
+                flags = I[I_FLAGS * cap + j];
+                ho = I[I_HOBJ * cap + j];
+                hs = I[I_HSHAPE * cap + j];
+                node = I[I_NODE * cap + j];
+                k = I[I_K * cap + j];
+            }
             if (RETR) {
                 rt = retrace_lane(P, node, k);
                 if (rt.old >= 0 && !rt.probe) ho = hs = -1;
             }
             traced = !((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed));  // else: pushed but never traced (System.jl:133)
             if (traced) {
-                const d3 pos{D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
-                dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+                d3 pos;
+                if (b == 0) {
+                    pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
+                    dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+                } else {
+                    pos = lm.get3(0);
+                    dir = lm.get3(3);
+                }
                 // per-lane column of LDS behind the block_alloc scratch: Lipschitz memory of the union children (bmo_lane.hpp sdf_any)
                 ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
 #if defined(BMO_DEV_TIMELINE)
@@ -594,6 +612,10 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     const int64_t ts = go_on ? jj : (int64_t)r1 + 2 * r;
                     if (ts < T.cap) write_ray(T, ts, next_ray(), (int32_t)cn, 0, -1, -1, child_flags, opl_next);
                     else atomicAdd(&P.ctr->overflow, 1ull);
+                    c_node = (int32_t)cn;
+                    c_k = 0;
+                    c_ho = c_hs = -1;
+                    c_fl = child_flags;
                     write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
                     kid_here = go_on;
                 } else {
@@ -610,6 +632,11 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     int32_t fl, ho, hs;
                     next_header(fl, ho, hs);
                     write_ray(N, jj, next_ray(), node, k + 1, ho, hs, fl, opl_next);
+                    c_node = node;
+                    c_k = k + 1;
+                    c_ho = ho;
+                    c_hs = hs;
+                    c_fl = fl;
                 } else if (!kid_here) {
                     N.i[I_NODE * N.cap + jj] = -1;  // no record of this beam at this level
                     alive = false;
