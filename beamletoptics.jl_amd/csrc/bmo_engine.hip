@@ -154,7 +154,7 @@ struct NextInLaneMem {
     __device__ void put(const d3& pos, const d3& dir, double n) const {
         lm.put3(0, pos);
         lm.put3(3, dir);
-        lm.m[6 * lm.stride] = n;
+        lm.m[7 * lm.stride] = n;  // (slot 6 is tracing_step's plate mark)
     }
 };
 
@@ -428,6 +428,12 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 if (b == 0) {
                     pos = {D[0 * cap + j], D[1 * cap + j], D[2 * cap + j]};
                     dir = {D[3 * cap + j], D[4 * cap + j], D[5 * cap + j]};
+                    // what the interaction will want behind the marches, into the lane memory with the same batch of loads (slots 7..10;
+                    // from level 1 on they are there already: the beam's constants do not change along a lane, children included)
+                    lm.m[7 * lm.stride] = D[6 * cap + j];
+                    lm.m[8 * lm.stride] = D[L::OPL * cap + j];
+                    lm.m[9 * lm.stride] = (double)P.nodes.li[node];
+                    lm.m[10 * lm.stride] = P.nodes.lambda[node];
                 } else {
                     pos = lm.get3(0);
                     dir = lm.get3(3);
@@ -495,12 +501,12 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 RayS ray;  // the interaction's share of the record
                 ray.pos = lm.get3(3);
                 ray.dir = dir;
-                ray.n = D[6 * cap + jj];
+                ray.n = lm.m[7 * lm.stride];
                 if (KIND == BMO_BEAM_POLARIZED)
                     for (int c = 0; c < 3; ++c) ray.E0[c] = {D[(11 + 2 * c) * cap + jj], D[(12 + 2 * c) * cap + jj]};
-                const double opl_acc = D[L::OPL * cap + jj];
-                li = P.nodes.li[node];
-                lambda = P.nodes.lambda[node];
+                const double opl_acc = lm.m[8 * lm.stride];
+                li = (int32_t)lm.m[9 * lm.stride];
+                lambda = lm.m[10 * lm.stride];
                 o.det = P.nodes.hit + (int64_t)node * 9;  // a detector hit ends the beam: its record goes straight to the node's slot
                 // (the ray that goes on is put into the lane memory — hit normal, origin and plate mark there are spent — as soon as a
                 //  branch of the interaction has it, and comes back from there when its record is written: bmo_lane.hpp NextInOut)
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             RayS r = o.next;  // (E0 of a PolarizedRay stays where it is)
             r.pos = lm.get3(0);
             r.dir = lm.get3(3);
-            r.n = lm.m[6 * lm.stride];
+            r.n = lm.m[7 * lm.stride];
             return r;
         };
         bool go_on = b + 1 < P.n_fuse;
@@ -616,6 +622,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     c_k = 0;
                     c_ho = c_hs = -1;
                     c_fl = child_flags;
+                    lm.m[8 * lm.stride] = opl_next;
                     write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
                     kid_here = go_on;
                 } else {
@@ -637,6 +644,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     c_ho = ho;
                     c_hs = hs;
                     c_fl = fl;
+                    lm.m[8 * lm.stride] = opl_next;
                 } else if (!kid_here) {
                     N.i[I_NODE * N.cap + jj] = -1;  // no record of this beam at this level
                     alive = false;

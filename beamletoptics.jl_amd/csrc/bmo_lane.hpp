@@ -818,7 +818,8 @@ inline int fill_candidates(const bmo_object* objects, int n_objects, const bmo_s
 //   3..5  origin of the ray (re-read where a candidate is set up instead of being held in registers across the marches)
 //   6     PLATE_BS: t of the coating's hit
 // The normal of a hit is evaluated once, for the hit that wins the tracing step (see tracing_step).
-constexpr int BMO_LANE_MEM = 7;
+constexpr int BMO_LANE_MEM = 11;  // 0..6: tracing_step (above); 7..10: the Beam step kernels' level loop (refractive index and optical path of
+                                  // the lane's ray, wavelength index and wavelength of its beam: bmo_engine.hip)
 struct LaneMem {
     double* m;
     int stride;
