@@ -1870,10 +1870,13 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         const int64_t m = cur.count;
         static const double keep_hi = getenv("BMO_KEEP_HI") ? atof(getenv("BMO_KEEP_HI")) : 0.9, keep_lo = getenv("BMO_KEEP_LO") ? atof(getenv("BMO_KEEP_LO")) : 0.6;
         static const int fuse_mid = getenv("BMO_FUSE_MID") ? atoi(getenv("BMO_FUSE_MID")) : 2, fuse_lo = getenv("BMO_FUSE_LO") ? atoi(getenv("BMO_FUSE_LO")) : 1;
-        // records per wave (StepParams::lane_shift): thinned out when the launch has fewer waves than the device has SIMDs to spare
+        // records per wave (StepParams::lane_shift).  BMO_THIN_WAVES=<n>: a launch with fewer than n waves spreads its records over more waves.
+        // Off by default: it took 6 % off the vignetted bundle while launches were level-synchronous, nothing since the beam splitters are
+        // handled in the loop, and it costs small batches dearly (100 rays through config 2: 0.84 ms against 0.55 — every wave on a CU of
+        // its own pays that CU's instruction- and scalar-cache warm-up): profiles/r03_ab_inwave.txt.
         int lane_shift = 6;
         {
-            static const int64_t thin_waves = getenv("BMO_THIN_WAVES") ? atoll(getenv("BMO_THIN_WAVES")) : 1024;
+            static const int64_t thin_waves = getenv("BMO_THIN_WAVES") ? atoll(getenv("BMO_THIN_WAVES")) : 0;
             while (lane_shift > 0 && ((m + (1ll << (lane_shift - 1)) - 1) >> (lane_shift - 1)) <= thin_waves) lane_shift -= 1;
         }
         // Beam kernels: every launch fuses all its levels, whatever share of its beams ends, and handles its beam splitters in the loop
