@@ -456,3 +456,40 @@ def test_children_born_in_a_continuation_get_the_full_r_max():
         same(a, b)
     for x in again + fresh:
         bmo.release(x)
+
+
+@pytest.mark.gpu
+def test_gauss_prefix_argument_checks():
+    """bmo_result_set_gauss_prefix refuses what it cannot mean: a Ray solution, a wrong root count, starts that do not begin at 0 or decrease."""
+    import ctypes as C
+
+    mm = 1e-3
+    lens = bmo.SphericalLens(60 * mm, -60 * mm, 4 * mm, 20 * mm, 1.5)
+    bmo.translate3d(lens, [0, 20 * mm, 0])
+    system = bmo.System([lens])
+    g = [bmo.GaussianBeamlet([0.1 * mm * i, 0, 0], [0, 1.0, 0], 1064e-9, 0.4 * mm, support=[1, 0, 0]) for i in range(3)]
+    for b in g:
+        bmo.solve_system(system, b)
+    sol = g[0]._solution
+    lib = sol.lib
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+    def call(n_roots, starts, segs, opl):
+        st = np.ascontiguousarray(starts, dtype=np.int32)
+        sg = np.ascontiguousarray(segs, dtype=np.float64)
+        op = np.ascontiguousarray(opl, dtype=np.float64)
+        return lib.bmo_result_set_gauss_prefix(sol.handle, n_roots, st.ctypes.data_as(ip), sg.ctypes.data_as(dp), op.ctypes.data_as(dp))
+
+    assert call(1, [0, 0], np.zeros((24, 0)), [0.0]) == 0                      # no earlier segments: fine
+    assert call(1, [0, 2], np.ones((24, 2)), [0.5]) == 0                       # replaces the prefix
+    assert call(2, [0, 0, 0], np.zeros((24, 0)), [0.0, 0.0]) != 0              # the solution has one root
+    assert call(1, [1, 1], np.zeros((24, 1)), [0.0]) != 0                      # starts begin at 0
+    assert call(1, [0, -1], np.zeros((24, 0)), [0.0]) != 0                     # ... and do not decrease
+    ray = bmo.Beam(bmo.Ray([0, 0, 0], [0, 1.0, 0], 1e-6))
+    bmo.solve_system(system, ray)
+    rsol = ray._solution
+    st = np.zeros(2, dtype=np.int32)
+    z = np.zeros(1)
+    assert rsol.lib.bmo_result_set_gauss_prefix(rsol.handle, 1, st.ctypes.data_as(ip), z.ctypes.data_as(dp), z.ctypes.data_as(dp)) != 0  # not a beamlet solution
+    for x in g + [ray]:
+        bmo.release(x)
