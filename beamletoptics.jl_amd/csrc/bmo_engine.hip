@@ -9,7 +9,7 @@
 //     its next record in place (same slot of the next in-place chunk); every wave runs its
 //     own level loop and notes how far it got (Chunk::wl).  A beam splitter met in the loop keeps
 //     its transmitted child in the lane and pushes the reflected one to the next launch's chunk
-//     (one reservation per wave); launches over few records spread them thinly over the waves.
+//     (one reservation per wave).
 //   * The scene tables (objects, shapes, triangles, n(lambda), candidate table) stay in global memory
 //     and are read with SCALAR loads through constant-address-space pointers: the wave works on one
 //     shape at a time, lanes that disagree on it take turns (bmo_lane.hpp "scalar scene access").
