@@ -165,6 +165,33 @@ def _check_source_hash(lib):
     if built != h.hexdigest():
         raise EngineMissing(f"{ENGINE_PATH} was not built from the sources in this tree (source hash {built!r} != {h.hexdigest()[:16]}...): "
                             "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    # ... nor one built with other compiler flags (bit parity needs -ffp-contract=off & co.): the build script's flag list decides
+    want = _wanted_flags_hash(root)
+    if want is not None:
+        try:
+            lib.bmo_build_flags_hash.restype = C.c_char_p
+            got = lib.bmo_build_flags_hash().decode()
+        except AttributeError:
+            got = None
+        if got != want:
+            raise EngineMissing(f"{ENGINE_PATH} was built with other compiler flags than __graft_entry__.HIP_FLAGS (flags hash {got!r} != {want!r}): "
+                                "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
+
+
+def _wanted_flags_hash(root):
+    """flags_hash() of the build script next to the package (None where there is none: an installed copy of the package)."""
+    path = os.path.join(root, "__graft_entry__.py")
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bmo_graft_entry", path)
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+        return mod.flags_hash()
+    except Exception:
+        return None
 
 
 def load_engine():

@@ -1973,7 +1973,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             ctxp->step_ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
-        hipLaunchKernelGGL(inwave_cap > 0 ? kern_inw : kern, dim3(n_blocks), dim3(BMO_BLOCK), lds_bytes, stream, P);
+        // (step_kernel_gauss handles P.inwave_cap itself: the GaussianBeamlet branch above assigns no kern_inw)
+        void (*const launch_kern)(StepParams) = (inwave_cap > 0 && kern_inw) ? kern_inw : kern;
+        if (!launch_kern) return fail(BMO_ERR_INTERNAL, "no step kernel selected for this beam kind / scene level");
+        hipLaunchKernelGGL(launch_kern, dim3(n_blocks), dim3(BMO_BLOCK), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps + 1], stream));
         HIP_TRY(hipMemcpyAsync(h_ctr_p, d_ctr, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -2301,6 +2304,10 @@ int bmo_version(void) { return BMO_ABI_VERSION; }
 const char* bmo_source_hash(void) {
     static const char tagged[] = "BMO_SOURCE_HASH=" BMO_SOURCE_HASH "\0BMO_FLAGS_HASH=" BMO_FLAGS_HASH;
     return tagged + 16;
+}
+const char* bmo_build_flags_hash(void) {
+    static const char tagged[] = "BMO_BUILT_WITH=" BMO_FLAGS_HASH;
+    return tagged + 15;
 }
 const char* bmo_last_error(void) { return g_err.c_str(); }
 

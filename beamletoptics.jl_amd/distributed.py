@@ -133,7 +133,8 @@ class HitExchange:
         wmax = max(max(self.widths), len(self.widths))
         dev = payloads[0].device
         buf = torch.zeros((rows + 1, wmax), dtype=torch.float64, device=dev)
-        buf[0, : len(payloads)] = torch.tensor([p.shape[0] for p in payloads], dtype=torch.float64)  # header: this rank's counts (host ints)
+        for d, p in enumerate(payloads):  # header: this rank's counts — host ints written by device-side fills (no pageable H2D copy per step)
+            buf[0, d].fill_(float(p.shape[0]))
         at = 1
         for p in payloads:
             buf[at: at + p.shape[0], : p.shape[1]] = p

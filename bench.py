@@ -7,9 +7,11 @@ compaction; results stay in HBM) and, for N > 1, the RCCL all-gather of the per-
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--workload c2|c2v|c3|c4|c5]
 
-N = 1 (default): BASELINE config 2 — 2^20 geometric Rays through the 10-element mesh+SDF miniscope scene with one beamsplitter.
-                 The same line also carries the other BASELINE configs at their per-GPU sizes (`configs`), a vignetted C2
-                 bundle, the PCIe-inclusive rates of the host-buffer boundary (`pcie`) and the CPU baseline.
+N = 1 (default): BASELINE config 2 on SURVEY §8(d)'s literal bundle (`c2s`) — 2^20 geometric Rays, Fibonacci disc of 0.8 x the first
+                 clear aperture along the axis + 2 mrad jitter, through the 10-element mesh+SDF miniscope scene with one beamsplitter.
+                 The same line also carries the other BASELINE configs at their per-GPU sizes (`configs`; `c2_cone` is the point-source
+                 cone bundle rounds 1-3 headlined), a vignetted C2 bundle, the PCIe-inclusive rates of the host-buffer boundary
+                 (`pcie`) and the CPU baseline (`cpu_baseline`, an object: the reference algorithm on one thread, the other two nested).
 N > 1:           BASELINE config 5 — the 32-element scene, 2^21 Rays per GPU (weak scaling: 2^24 at 8 GPUs), contiguous shards,
                  RCCL all-gather of the detector hit lists.  Started either by the driver under torch.distributed.run, or as
                  plain `python bench.py --gpus N`: the N ranks are then started as child processes (before this process touches
@@ -40,7 +42,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rays", type=int, default=0, help="root beams per GPU (0 = the BASELINE size of the workload)")
-    ap.add_argument("--workload", default="", help="c2 | c2s | c2v | c3 | c4 | c5 (default: c2 at N = 1, c5 at N > 1)")
+    ap.add_argument("--workload", default="", help="c2s | c2 | c2v | c3 | c4 | c5 (default: c2s at N = 1, c5 at N > 1)")
     ap.add_argument("--r-max", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=16384, help="rays for the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the other configs and the PCIe-inclusive rates")
@@ -79,12 +81,13 @@ def workload(name, n, rank=0):
     lg = "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n)
     if name == "c2":
         return scenes.c2_scene()[0], scenes.c2_bundle(n, seed=SEED + rank), (
-            f"BASELINE config 2: {lg} geometric Rays per GPU (0.3 mm object disc, 0.25 rad cone, seed {SEED} + rank) through the 10-element "
-            "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors")
+            f"config 2 scene, point-source cone bundle (the headline of rounds 1-3): {lg} geometric Rays per GPU (0.3 mm object disc, 0.25 rad cone, seed {SEED} + rank) "
+            "through the 10-element mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors")
     if name == "c2s":
         return scenes.c2_scene()[0], scenes.c2_survey_bundle(n, seed=SEED + rank), (
-            f"config 2 scene, SURVEY 8(d)'s literal bundle: {lg} geometric Rays per GPU, Fibonacci disc of 0.8 x the first clear aperture (1.83 mm) at the object "
-            "plane, directions along the optical axis + a per-ray jitter of at most 2 mrad")
+            f"BASELINE config 2 on SURVEY 8(d)'s literal bundle: {lg} geometric Rays per GPU, Fibonacci disc (BeamGroups.jl:232-243) of 0.8 x the first clear aperture "
+            f"(1.83 mm) at the object plane, directions along the optical axis + a per-ray jitter of at most 2 mrad (PCG64 seed {SEED} + rank), through the 10-element "
+            "mesh+SDF miniscope scene with one ThinBeamsplitter and two Spotdetectors")
     if name == "c2v":
         return scenes.c2_scene()[0], scenes.c2_vignetted_bundle(n, seed=SEED + rank), (
             f"config 2 scene, vignetted bundle: {lg} geometric Rays per GPU, 2.0 mm object disc (0.87 x the first aperture) and 0.6 rad cone: 10 % of the rays miss the first lens, 45 % reach the splitter, the rest "
@@ -102,6 +105,7 @@ def workload(name, n, rank=0):
     raise SystemExit(f"unknown workload {name!r}")
 
 
+CONFIG_KEY = {"c2": "c2_cone"}  # key of a workload in the line's `configs`
 DEFAULT_RAYS = {"c2": 1 << 20, "c2s": 1 << 20, "c2v": 1 << 20, "c3": 1 << 20, "c4": 1 << 18, "c5": 1 << 21}
 
 
@@ -158,7 +162,9 @@ def measured_traffic(name, n, r_max):
     """HBM bytes per SOLVE of the workload's step kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
     this timed process): FETCH_SIZE x 2 + WRITE_SIZE, separate passes (MI355X_MICROARCH.md "HBM"), same command, default size only.
     roofline_of divides by the launches per solve of THIS run, like the algorithmic bytes."""
-    tp = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(tp):
+        tp = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if not os.path.exists(tp) or n != DEFAULT_RAYS.get(name) or r_max != 100:
         return None, None
     tj = json.load(open(tp)).get(name)
@@ -176,6 +182,9 @@ def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=N
         "traffic": traffic / per_step if traffic is not None else None,
         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
         "kernel": KERNEL_NAME[case.kind], "launches_per_step": per_step, "avg_launch_ms": kernel_ms / max(launches, 1),
+        # (the launches of a solve are very unequal — the first one carries the roots through up to 32 levels, the later ones the
+        #  reflected children —, so the per-SOLVE kernel time is the basis of `achieved`; avg_launch_ms is informational)
+        "kernel_ms_per_solve": kernel_ms / max(steps, 1), "algorithmic_bytes_per_solve": alg,
         "algorithmic_bytes_per_launch": alg / per_step,
         "note": "path is FP64-VALU/latency bound (SURVEY.md §8d): algorithmic HBM bytes are %d B/bounce + the detector records; "
                 "see DESIGN.md §4 for the VALU-side accounting" % BYTES_PER_BOUNCE[case.kind],
@@ -193,11 +202,11 @@ def cpu_model():
 
 
 def cpu_baseline(case, sample, r_max):
-    """Three CPU figures on bounded samples of the same workload, timed on this box's host cores (rank 0, N = 1 only):
-      [0] the oracle (op-for-op restatement of the reference algorithm, incl. its 1000-iteration misses) on ONE thread — the
+    """ONE object holding three CPU figures on bounded samples of the same workload, timed on this box's host cores (rank 0, N = 1 only):
+      headline: the oracle (op-for-op restatement of the reference algorithm, incl. its 1000-iteration misses) on ONE thread — the
           reference's trace loop is serial (System.jl:463-468);                                      kind "port"
-      [1] the oracle, plain parallel-for over rays on every host core;                                   kind "port"
-      [2] the engine's own lane code compiled for the host (tests/emu: same culls, same shortcuts, same arithmetic as the HIP
+      "all_cores": the oracle, plain parallel-for over rays on every host core;                           kind "port"
+      "lane_code_all_cores": the engine's own lane code compiled for the host (tests/emu: same culls, same shortcuts, same arithmetic as the HIP
           kernels) on every host core — the "same algorithm on a CPU" figure that separates what the GPU buys from what the
           result-preserving shortcuts buy.                                                             kind "port"
     """
@@ -242,7 +251,12 @@ def cpu_baseline(case, sample, r_max):
                 "what": "the engine's lane code (csrc/bmo_lane.hpp: culls, prunes and child skips on) compiled for the host, one sub-bundle per core",
                 "sample": f"every (N/{b.n})-th ray of the same bundle, same scene ({calls} reference intersect3d calls counted, {dt:.1f} s wall)",
                 "rays_per_s": b.n / dt, "nproc": nproc, "cpu": model})
-    return out
+    # ONE object (the driver's parser keeps `cpu_baseline` only as an object): the headline is the reference algorithm on one thread —
+    # the reference's trace loop is serial (System.jl:463-468) —, the other two figures are nested inside it
+    head = dict(out[0])
+    head["all_cores"] = out[1]
+    head["lane_code_all_cores"] = out[2]
+    return head
 
 
 def pcie_rates(case, r_max, calls):
@@ -342,7 +356,7 @@ def main():
     if multi:
         from bmo_amd import distributed as bd
 
-    name = args.workload or ("c5" if multi else "c2")
+    name = args.workload or ("c5" if multi else "c2s")
     n_local = args.rays or DEFAULT_RAYS[name]
     # Weak scaling: the global bundle is the concatenation, in rank order, of one complete bundle per GPU (same disc and cone
     # distribution, directions drawn from seed + rank), so every rank traces the same amount of work and its contiguous shard keeps
@@ -452,18 +466,23 @@ def main():
         if not multi and not args.no_extras:
             out["pcie"] = pcie_rates(case, args.r_max, calls)
         if args.cpu_sample > 0 and not multi:  # the CPU baseline is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(case, min(args.cpu_sample, n_local), args.r_max)
+            cb = cpu_baseline(case, min(args.cpu_sample, n_local), args.r_max)
+            out["cpu_baseline"] = cb
+            # BASELINE.md holds no published number for this metric (the reference publishes none); its §3 names the baseline to time
+            # beside the GPU: B1, the reference algorithm on one host thread.  vs_baseline is the ratio to THAT measurement.
+            out["vs_baseline"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+            out["vs_baseline_of"] = "cpu_baseline.value (BASELINE.md §3 B1: the reference algorithm restated op for op, one host thread; nothing is published upstream)"
     case.close()
     if rank == 0 and not multi and not args.no_extras:
         # the other BASELINE configs at their per-GPU sizes, and the vignetted C2 bundle: 3 resident solves each after 1 warm-up
         cfgs = {}
-        for other in ("c2s", "c2v", "c3", "c4", "c5"):
+        for other in ("c2s", "c2", "c2v", "c3", "c4", "c5"):
             if other == name:
                 continue
             oc = Case(bmo, other, DEFAULT_RAYS[other], device_ord)
             odt, okms, onl, c = oc.measure(args.r_max, 3, 1)
             rl = roofline_of(oc, c, okms, onl, 3, *measured_traffic(other, DEFAULT_RAYS[other], args.r_max))
-            cfgs[other] = {"workload": oc.text, "beams": oc.bundle.n, "ms": odt / 3 * 1e3, "kernel_ms": okms / 3, "launches": onl // 3,
+            cfgs[CONFIG_KEY.get(other, other)] = {"workload": oc.text, "beams": oc.bundle.n, "ms": odt / 3 * 1e3, "kernel_ms": okms / 3, "launches": onl // 3,
                            "intersections_per_s": c["calls"] * 3 / odt, ("beamlets_per_s" if oc.kind == 2 else "rays_per_s"): oc.bundle.n * 3 / odt,
                            "segments": c["segments"], "beam_nodes": c["nodes"], "detector_hits": c["hits"],
                            "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"], "traffic": rl["traffic"], "traffic_unit": "bytes per launch",

@@ -280,6 +280,10 @@ const char* bmo_last_error(void);
    header, in that order), recorded by the build; "" for a build that did not record one.  The host side compares it with the sources
    it finds next to the library and refuses a stale binary (there is no reference counterpart: housekeeping of the boundary). */
 const char* bmo_source_hash(void);
+/* First 16 hex digits of the SHA-256 of the compiler flag list the library was built with (__graft_entry__.HIP_FLAGS joined by
+   blanks); "" for a build that did not record one.  Bit-level parity with the reference depends on some of those flags
+   (-ffp-contract=off: Julia never contracts a*b+c), so the host side refuses a library built with other flags, like a stale one. */
+const char* bmo_build_flags_hash(void);
 
 /* Number of usable HIP devices (0 = none). */
 int bmo_device_count(void);

@@ -1,7 +1,7 @@
 """Collect gpurun_out/prof_round/ (tools/profile_round.sh) into profiles/<tag>_*: the step kernels' rows of the rocprofv3 kernel stats, the
 bench line measured under the profiler, the counter summaries, and <tag>_traffic.json (what bench.py's `traffic` fields read).
     python tools/collect_profiles.py r03"""
-import csv, glob, json, os, re, sys
+import ast, csv, glob, json, os, re, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_round")
@@ -26,8 +26,9 @@ for wdir in sorted(glob.glob(src + "/*/")):
             continue
         m = re.search(r"total ms [\d.]+ (\{.*\})", open(p).read())
         if m:
-            tot.update({k: float(v) for k, v in eval(m.group(1)).items()})
+            tot.update({k: float(v) for k, v in ast.literal_eval(m.group(1)).items()})
         launches = sum(1 for ln in open(p) if re.match(r"^\d+ \d+ ", ln))
+        assert tot.get("launches", launches) == launches, f"{w}: the FETCH and WRITE passes saw different launch counts ({tot['launches']} vs {launches})"
         tot["launches"] = launches
     if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B); bench.py doubles FETCH_SIZE (MI355X_MICROARCH.md "HBM": gfx950 counts
