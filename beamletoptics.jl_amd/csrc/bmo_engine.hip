@@ -190,6 +190,10 @@ struct NodeArrays {
 };
 
 // Tables of the previous solution a retrace re-walks (System.jl:188-255), indexed by ITS node ids; all device pointers.
+struct OldChunk {  // one chunk of the previous solution's segment log
+    const double* d;
+    int64_t cap;
+};
 struct OldSolution {
     const int32_t* nseg;         // stored rays per beam
     const int32_t* status;       // BMO_NODE_SPLIT <=> the beam has (two) children
@@ -197,7 +201,22 @@ struct OldSolution {
     const int32_t* rec_start;    // exclusive scan of nseg
     const int32_t* rec_obj;      // [rec_start[node] + k]: object of the stored intersection of ray k, -1 = none
     const double* aux;           // Gaussian: [node][4] = l0, w0, Re E0, Im E0
+    // where the stored rays are: record k of beam `node` is slot (loc & 2^40 - 1) of chunk (loc >> 40), loc = rec_loc[rec_start[node] + k].
+    // Two situations read stored RAYS, not only the stored objects: children the reference keeps although the re-walk of their parent
+    // ended in a `nothing` interaction before the splitter (they start from their stored first ray, System.jl:232-240), and a beamlet
+    // that splits before the end of its stored path (its children are sized with the stale tail attached, ThinBeamsplitter.jl:125).
+    const int64_t* rec_loc;
+    const OldChunk* chunks;
 };
+constexpr int OLD_LOC_SHIFT = 40;
+// planes and slot of stored record k of beam `node` of the previous solution
+__device__ __forceinline__ const double* old_record(const OldSolution& O, int32_t node, int32_t k, int64_t& cap, int64_t& slot) {
+    const int64_t loc = O.rec_loc[(int64_t)O.rec_start[node] + k];
+    const OldChunk c = O.chunks[loc >> OLD_LOC_SHIFT];
+    cap = c.cap;
+    slot = loc & (((int64_t)1 << OLD_LOC_SHIFT) - 1);
+    return c.d;
+}
 
 #if !defined(BMO_MAX_FUSE)
 #define BMO_MAX_FUSE 32
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         // ---- the interaction and the record of this level
         int64_t jj = j;
         asm volatile("" : "+v"(jj));
-        bool survive = false, split = false, still = false, old_kids = false;
+        bool survive = false, split = false, still = false, old_kids = false, stale_kids = false;
         double opl_next = 0.0, lambda = 0.0;
         int32_t li = 0;
         StepOut o;
@@ -521,6 +540,28 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     opl_next = opl_acc + X.t * ray.n;
                 } else {
                     status |= BMO_NODE_STOPPED;
+                    if (RETR && rt.old >= 0 && rt.probe && !rt.missed && P.old.first_child[rt.old] >= 0) {
+                        // The re-walk ends here in a `nothing` interaction, before the splitter the stored beam ended on: the reference cuts the
+                        // tail but KEEPS the children (cleanup_children stays false, System.jl:232-240); solve_system! then retraces each of them
+                        // from its stored first ray (System.jl:446-458).  The two stored heads take the places a splitter's children have: the
+                        // transmitted one in the lane memory (o.next for the field vector), the reflected one in o.refl.
+                        stale_kids = true;
+                        opl_next = opl_acc + X.t * ray.n;  // optical_path_length(parent): every ray of the cut beam up to this hit (Beam.jl:137-149)
+                        const int32_t oc = P.old.first_child[rt.old];
+                        int64_t hc, hs;
+                        const double* H = old_record(P.old, oc, 0, hc, hs);
+                        lm.put3(0, d3{H[0 * hc + hs], H[1 * hc + hs], H[2 * hc + hs]});
+                        lm.put3(3, d3{H[3 * hc + hs], H[4 * hc + hs], H[5 * hc + hs]});
+                        lm.m[7 * lm.stride] = H[6 * hc + hs];
+                        if (KIND == BMO_BEAM_POLARIZED)
+                            for (int c = 0; c < 3; ++c) o.next.E0[c] = {H[(11 + 2 * c) * hc + hs], H[(12 + 2 * c) * hc + hs]};
+                        H = old_record(P.old, oc + 1, 0, hc, hs);
+                        o.refl.pos = d3{H[0 * hc + hs], H[1 * hc + hs], H[2 * hc + hs]};
+                        o.refl.dir = d3{H[3 * hc + hs], H[4 * hc + hs], H[5 * hc + hs]};
+                        o.refl.n = H[6 * hc + hs];
+                        if (KIND == BMO_BEAM_POLARIZED)
+                            for (int c = 0; c < 3; ++c) o.refl.E0[c] = {H[(11 + 2 * c) * hc + hs], H[(12 + 2 * c) * hc + hs]};
+                    }
                 }
             }
             // intersection part of this record
@@ -532,8 +573,11 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             I[I_SHAPE * cap + jj] = X.shape;
             if (RETR) {
                 still = rt.old >= 0 && rt.probe && !rt.missed;  // the stored path held at this ray
-                old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
-                if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+                old_kids = still && P.old.first_child[rt.old] >= 0;  // (not the SPLIT status: kept stale children hang on a beam that did not split)
+                if (stale_kids) {  // from here on like a splitter's children, but the beam did not split: no BMO_NODE_SPLIT
+                    status |= BMO_NODE_RETRACE_STALE;
+                    split = true;
+                }
                 if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
             }
             if (!survive) {  // node ends here
@@ -787,6 +831,28 @@ struct GaussRecDev {
         return g;
     }
 };
+// retrace: the stored rays behind the one a re-walking beamlet is at (bmo_lane.hpp gauss_step_rec `tail`), read from the previous
+// solution's log
+struct GaussTailDev {
+    const OldSolution& O;
+    int32_t old, k, old_n;
+    __device__ int more() const { return old >= 0 ? old_n - (k + 1) : 0; }
+    __device__ double t(int q) const {
+        int64_t c, s;
+        const double* D = old_record(O, old, k + 1 + q, c, s);
+        return D[7 * c + s];
+    }
+    __device__ RayS ray(int q, int r) const {
+        int64_t c, s;
+        const double* D = old_record(O, old, k + 1 + q, c, s);
+        const int64_t b = 11 * (int64_t)r;
+        RayS x;
+        x.pos = {D[(b + 0) * c + s], D[(b + 1) * c + s], D[(b + 2) * c + s]};
+        x.dir = {D[(b + 3) * c + s], D[(b + 4) * c + s], D[(b + 5) * c + s]};
+        x.n = D[(b + 6) * c + s];
+        return x;
+    }
+};
 // retrace: a beamlet that re-walks its stored path without a probe starts without a hint
 struct GaussRecDevNoHint : GaussRecDev {
     __device__ int32_t hint_obj() const { return -1; }
@@ -881,6 +947,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
                 if (RETR && no_hint) {
                     GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap}};
                     gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
+                } else if (RETR) {
+                    const GaussTailDev tail{P.old, rt.old, k, rt.old_n};
+                    gauss_step_rec<EXT, RETR, GaussRecDev, GaussTailDev>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed, tail);
                 } else {
                     gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
                 }
@@ -895,11 +964,37 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
             I[I_SHAPE * cap + j] = o.hit_shape;
             if (RETR) {
                 still = rt.old >= 0 && rt.probe && !rt.missed;
-                old_kids = still && (P.old.status[rt.old] & BMO_NODE_SPLIT);
-                if (!survive && old_kids && !split) status |= BMO_NODE_RETRACE_STALE;
+                old_kids = still && P.old.first_child[rt.old] >= 0;  // (not the SPLIT status: kept stale children hang on a beamlet that did not split)
+                if (!survive && old_kids && !split && !(flags & F_DEAD)) {
+                    // The re-walk ends in a `nothing` interaction before the splitter the stored beamlet ended on: the reference keeps the children
+                    // (System.jl:393-400) and retraces each from its stored first rays.  They take a splitter's children's places: the transmitted
+                    // one's rays in the next level's record, the reflected one's in the staging planes; w0 and E0 stay the stored ones.
+                    status |= BMO_NODE_RETRACE_STALE;
+                    const int32_t oc = P.old.first_child[rt.old];
+                    BMO_NOUNROLL
+                    for (int w = 0; w < 2; ++w) {
+                        int64_t hc, hs;
+                        const double* H = old_record(P.old, oc + w, 0, hc, hs);
+                        BMO_NOUNROLL
+                        for (int r = 0; r < 3; ++r) {
+                            const int64_t b11 = 11 * (int64_t)r;
+                            RayS x;
+                            x.pos = {H[(b11 + 0) * hc + hs], H[(b11 + 1) * hc + hs], H[(b11 + 2) * hc + hs]};
+                            x.dir = {H[(b11 + 3) * hc + hs], H[(b11 + 4) * hc + hs], H[(b11 + 5) * hc + hs]};
+                            x.n = H[(b11 + 6) * hc + hs];
+                            if (w == 0) rec.put_next(r, x);
+                            else rec.put_refl(r, x);
+                        }
+                    }
+                    o.child_l0 = o.lenA + P.nodes.aux[(int64_t)node * 4 + 0];  // length(parent chief): its rays up to this hit + its own parents (Beam.jl:125-130)
+                    o.child_w0 = P.old.aux[(int64_t)oc * 4 + 1];
+                    o.Et = {P.old.aux[(int64_t)oc * 4 + 2], P.old.aux[(int64_t)oc * 4 + 3]};
+                    o.Er = {P.old.aux[(int64_t)(oc + 1) * 4 + 2], P.old.aux[(int64_t)(oc + 1) * 4 + 3]};
+                    split = true;  // from here on like a splitter's children, but the beamlet did not split: no BMO_NODE_SPLIT
+                }
                 // a split before the end of the stored path: the reference sizes the children (w0, E0) with the stale tail still attached
-                // to the beamlet (gauss_parameters(gauss, length(gauss)), ThinBeamsplitter.jl:125); here they are evaluated at the split
-                if (split && still && k + 1 < rt.old_n) status |= BMO_NODE_RETRACE_STALE;
+                // to the beamlet (gauss_parameters(gauss, length(gauss)), ThinBeamsplitter.jl:125) — gauss_step_rec's `tail`; the flag stays as a note
+                if ((status & BMO_NODE_SPLIT) && still && k + 1 < rt.old_n) status |= BMO_NODE_RETRACE_STALE;
                 if (rt.old >= 0 && !(survive && still && k + 1 < rt.old_n)) P.nodes.old[node] = -1;
             }
             if (!survive) {
@@ -1087,13 +1182,15 @@ __global__ void bin_planes_kernel(const double* __restrict__ in, const int32_t* 
 }
 
 // retrace tables of a finished solution
-__global__ void old_obj_scatter_kernel(Chunk c, const int32_t* __restrict__ rec_start, int32_t* __restrict__ rec_obj) {
+__global__ void old_obj_scatter_kernel(Chunk c, int32_t chunk_index, const int32_t* __restrict__ rec_start, int32_t* __restrict__ rec_obj,
+                                       int64_t* __restrict__ rec_loc) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c.count) return;
     const int32_t node = chunk_node(c, j);
     if (node < 0) return;  // hole of a fused level
     const int32_t k = c.i[I_K * c.cap + j];
     rec_obj[(int64_t)rec_start[node] + k] = c.i[I_OBJ * c.cap + j];
+    rec_loc[(int64_t)rec_start[node] + k] = ((int64_t)chunk_index << OLD_LOC_SHIFT) | j;
 }
 __global__ void old_first_child_kernel(const int32_t* __restrict__ parent, const unsigned long long* __restrict__ key, int64_t n, int32_t* __restrict__ first_child) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1547,7 +1644,7 @@ struct bmo_trace_result {
     // tables a later bmo_retrace of THIS solution needs, built on first use (OldSolution)
     std::mutex rt_mu;
     bool rt_built = false;
-    DevBuf rt_rec_start, rt_rec_obj, rt_first_child;
+    DevBuf rt_rec_start, rt_rec_obj, rt_first_child, rt_rec_loc, rt_chunks;
     std::vector<int64_t> det_count, det_offset;
     // host views (filled by bmo_result_view / bmo_result_view_select), all page-locked; each part is materialised on first request
     bool nodes_viewed = false, hits_viewed = false;
@@ -1568,18 +1665,25 @@ int build_retrace_tables(bmo_trace_result* prev, hipStream_t stream) {
     if (nr >= (int64_t)1 << 31) return fail(BMO_ERR_UNSUPPORTED, "retrace: previous solution has more than 2^31 segments");
     int rc;
     if ((rc = prev->rt_rec_start.alloc((size_t)std::max<int64_t>(nn, 1) * 4)) || (rc = prev->rt_rec_obj.alloc((size_t)std::max<int64_t>(nr, 1) * 4)) ||
-        (rc = prev->rt_first_child.alloc((size_t)std::max<int64_t>(nn, 1) * 4)))
+        (rc = prev->rt_first_child.alloc((size_t)std::max<int64_t>(nn, 1) * 4)) || (rc = prev->rt_rec_loc.alloc((size_t)std::max<int64_t>(nr, 1) * 8)) ||
+        (rc = prev->rt_chunks.alloc(std::max<size_t>(prev->chunks.size(), 1) * sizeof(OldChunk))))
         return rc;
+    if (prev->chunks.size() >= ((size_t)1 << (63 - OLD_LOC_SHIFT))) return fail(BMO_ERR_UNSUPPORTED, "retrace: previous solution has too many log chunks");
     if (nn > 0) {
         DevBuf tmp;
         size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const int32_t*)prev->n_nseg.p, (int32_t*)prev->rt_rec_start.p, (int)nn, stream));
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, (const int32_t*)prev->n_nseg.p, (int32_t*)prev->rt_rec_start.p, (int)nn, stream));
-        for (const Chunk& c : prev->chunks)
+        std::vector<OldChunk> oc(prev->chunks.size());
+        for (size_t q = 0; q < prev->chunks.size(); ++q) oc[q] = OldChunk{prev->chunks[q].d, prev->chunks[q].cap};
+        if (!oc.empty()) HIP_TRY(hipMemcpyAsync(prev->rt_chunks.p, oc.data(), oc.size() * sizeof(OldChunk), hipMemcpyHostToDevice, stream));
+        for (size_t q = 0; q < prev->chunks.size(); ++q) {
+            const Chunk& c = prev->chunks[q];
             if (c.count > 0)
-                hipLaunchKernelGGL(old_obj_scatter_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)prev->rt_rec_start.p,
-                                   (int32_t*)prev->rt_rec_obj.p);
+                hipLaunchKernelGGL(old_obj_scatter_kernel, dim3((unsigned)((c.count + 255) / 256)), dim3(256), 0, stream, c, (int32_t)q,
+                                   (const int32_t*)prev->rt_rec_start.p, (int32_t*)prev->rt_rec_obj.p, (int64_t*)prev->rt_rec_loc.p);
+        }
         HIP_TRY(hipMemsetAsync(prev->rt_first_child.p, 0xFF, (size_t)nn * 4, stream));
         hipLaunchKernelGGL(old_first_child_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, (const int32_t*)prev->n_parent.p,
                            (const unsigned long long*)prev->n_key.p, nn, (int32_t*)prev->rt_first_child.p);
@@ -1807,6 +1911,8 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         old_tab.rec_start = (const int32_t*)prev->rt_rec_start.p;
         old_tab.rec_obj = (const int32_t*)prev->rt_rec_obj.p;
         old_tab.aux = (const double*)prev->n_aux.p;
+        old_tab.rec_loc = (const int64_t*)prev->rt_rec_loc.p;
+        old_tab.chunks = (const OldChunk*)prev->rt_chunks.p;
     }
     if (has_split && n > 0 && (rc = tbits_buf.alloc((size_t)n * 8))) return rc;
     if (n > 0) {

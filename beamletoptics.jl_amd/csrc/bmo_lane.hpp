@@ -1675,9 +1675,20 @@ BMO_HD Hit pick_hit(int r, const Hit& a, const Hit& b, const Hit& c) {
 // a ray is fetched when its march starts and its hit is put back when the march ends, so nothing of the beamlet but a few integers
 // is live across the three sphere-tracing marches.  On the GPU the backing store is the record itself (HBM / L2); held in
 // registers, the 3 rays + 3 hits were spilled around every march (1.5 KB of scratch per lane, 5 x the algorithmic HBM traffic).
-template <int EXT, bool RETR, class Rec>
+//
+// `tail` (retrace): the stored rays still attached behind the one a re-walking beamlet is at — more() of them, chief hit length t(q)
+// (+Inf: no intersection) and rays ray(q, 0 | 1 | 2) of the q-th.  A beamlet that meets a splitter BEFORE the end of its stored path has
+// its children sized by gauss_parameters(gauss, length(gauss)) (ThinBeamsplitter.jl:125) while that stale tail is still part of the
+// beamlet: retrace_system! deletes it only after its loop (System.jl:417-421).  length() and point_on_beam() then run over the new rays up
+// to this one AND the stale ones behind it (Beam.jl:125-169, 177-205), and the waist comes from the rays point_on_beam lands on.
+struct NoStaleTail {
+    BMO_HD int more() const { return 0; }
+    BMO_HD double t(int) const { return kinf(); }
+    BMO_HD RayS ray(int, int) const { return RayS{}; }
+};
+template <int EXT, bool RETR, class Rec, class Tail = NoStaleTail>
 BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
-                           int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
+                           int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr, const Tail& tail = Tail()) {
     o.outcome = OUT_MISS;
     o.status = 0;
     o.hint_obj = o.hint_shape = -1;
@@ -1688,6 +1699,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
     // three hit records written: a marched ray writes its own, the rays behind a miss are written as `no hit` there (clearing all three up
     // front and overwriting them cost 96 B of HBM writes per beamlet and level)
     bool all_hit = true;
+    bool held = RETR && probe;  // the stored path holds at this ray (set back when the probe fails)
     int32_t hint_obj = rec.hint_obj(), hint_shape = rec.hint_shape();
     int32_t sh0 = -1, sh1 = -1, sh2 = -1, ob0 = -1;
     BMO_NOUNROLL
@@ -1718,6 +1730,7 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
             // the stored path holds only if all three rays still hit the same shape (System.jl:377-392)
             if (sh0 >= 0 && sh1 >= 0 && sh2 >= 0 && sh0 == sh1 && sh1 == sh2) break;
             if (probe_missed) *probe_missed = true;
+            held = false;
             rec.clear_hits();
             sh0 = sh1 = sh2 = ob0 = -1;
             if (!fresh_allowed) {
@@ -1816,10 +1829,54 @@ BMO_HD void gauss_step_rec(const SceneView& S, Rec& rec, GaussOut& o, uint32_t& 
     }
     // splitter: ThinBeamsplitter.jl:117-168 (+ PlateBeamsplitter.jl:230-275, CubeBeamsplitter.jl:94-121 via interact's split modes)
     const GaussIn g = rec.load();
-    const double t_total = (g.lenA + Xc.t) + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
-    const double w0 = gauss_w0_at(g, t_total, g.lenB);
+    const double len_here = g.lenA + Xc.t;  // length_rays up to this hit (Beam.jl:160-169)
+    double w0;
+    const int more = (RETR && held) ? tail.more() : 0;
+    if (RETR && more > 0) {
+        // the stale tail is still attached (see `tail` above): length(gauss) and point_on_beam run over it too
+        double l = len_here;
+        BMO_NOUNROLL
+        for (int q = 0; q < more; ++q) {
+            const double tq = tail.t(q);
+            if (!(tq < kinf())) break;  // a ray without intersection ends length_rays
+            l += tq;
+        }
+        const double t_total = l + g.l0;
+        // point_on_beam(chief, t_total) Beam.jl:177-205: rays 1..i-1 are in lenB, ray i is this one, then the stale ones; the last ray
+        // of the beam is never tested (index == numEl: break)
+        double temp = g.lenB + Xc.t;
+        int at = -2;  // -1: this ray; q >= 0: stale ray q
+        d3 p0{0, 0, 0};
+        if (t_total < temp) {
+            const double b = temp - t_total;
+            p0 = axpy3(g.c.pos, Xc.t - b, g.c.dir);
+            at = -1;
+        }
+        BMO_NOUNROLL
+        for (int q = 0; q + 1 < more && at == -2; ++q) {
+            const double len = tail.t(q);
+            temp += len;
+            if (t_total < temp) {
+                const double b = temp - t_total;
+                const RayS cq = tail.ray(q, 0);
+                p0 = axpy3(cq.pos, len - b, cq.dir);
+                at = q;
+            }
+        }
+        if (at == -2) {
+            at = more - 1;
+            const RayS cq = tail.ray(at, 0);
+            p0 = axpy3(cq.pos, t_total - temp, cq.dir);
+        }
+        const RayS pc = at < 0 ? g.c : tail.ray(at, 0), pw = at < 0 ? g.w : tail.ray(at, 1), pd = at < 0 ? g.d : tail.ray(at, 2);
+        double w_, R_, psi_;
+        gauss_parameters_at(pc, pw, pd, p0, g.lambda, w_, R_, psi_, w0);
+    } else {
+        const double t_total = len_here + g.l0;  // length(gauss) = length_rays + length_parent (Beam.jl:125-130)
+        w0 = gauss_w0_at(g, t_total, g.lenB);
+    }
     o.child_w0 = w0;
-    o.child_l0 = t_total;
+    o.child_l0 = len_here + g.l0;  // length(parent chief) as the children will see it: the tail is gone by then
     const double ratio = g.w0 / w0;
     o.Et = cmulr(rmul(ob.transmittance, g.E0), ratio);
     o.Er = cmulr(rmul(ob.reflectance, g.E0), ratio);
@@ -1845,11 +1902,11 @@ struct GaussRecLocal {
     BMO_HD GaussIn load() const { return g; }
     BMO_HD GaussAcc acc() const { return GaussAcc{g.lenA, g.lenB, g.oplC, g.oplW, g.oplD, g.lambda, g.l0, g.w0, g.E0, g.li}; }
 };
-template <int EXT, bool RETR = false>
+template <int EXT, bool RETR = false, class Tail = NoStaleTail>
 BMO_HD void gauss_step(const SceneView& S, const GaussIn& g, GaussOut& o, uint32_t& calls, ChildCache& cc, const LaneMem& lm, bool probe = false,
-                       int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr) {
+                       int32_t probe_obj = -1, bool fresh_allowed = true, bool* probe_missed = nullptr, const Tail& tail = Tail()) {
     GaussRecLocal rec{g, {no_hit(), no_hit(), no_hit()}, {}, {}};
-    gauss_step_rec<EXT, RETR>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed);
+    gauss_step_rec<EXT, RETR, GaussRecLocal, Tail>(S, rec, o, calls, cc, lm, probe, probe_obj, fresh_allowed, probe_missed, tail);
     o.nc = rec.nxt[0];
     o.nw = rec.nxt[1];
     o.nd = rec.nxt[2];

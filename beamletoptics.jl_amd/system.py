@@ -505,12 +505,13 @@ def _trace_open_leaves(system, roots, r_max, device):
             open_beams.append(b)
     while open_beams:
         open_beams = _continue_open_beams(system, open_beams, r_max, device)
-    queue = list(roots)
-    while queue:
-        b = queue.pop(0)
-        queue.extend(b.children)
-        for det, row in b.__dict__.pop("_pending_hits", []):
-            det.data = np.concatenate([det.data, np.asarray(row)[None, :]], axis=0)
+    for root in roots:  # solve_system!(bg) finishes root 1's whole tree before it starts root 2 (System.jl:463-468): one BFS per root
+        queue = [root]
+        while queue:
+            b = queue.pop(0)
+            queue.extend(b.children)
+            for det, row in b.__dict__.pop("_pending_hits", []):
+                det.data = np.concatenate([det.data, np.asarray(row)[None, :]], axis=0)
     for b in roots:  # the resident solution no longer describes these beams: the next solve traces them afresh
         sol = getattr(b, "_solution", None)
         if sol is not None:

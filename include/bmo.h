@@ -62,14 +62,15 @@ enum bmo_node_status {
     BMO_NODE_GAUSS_DIVERGED = 64, /* chief/waist/div did not hit same shape (System.jl:298-304) */
     BMO_NODE_BLOCKED = 128,   /* PolarizationFilter blocked ray (PolarizationFilter.jl:42) */
     BMO_NODE_ERR_ORTHO = 256, /* E0 not orthogonal to dir, ErrorException (PolarizedRays.jl:54-56) */
-    BMO_NODE_RETRACE_STALE = 512 /* retrace only: the stored beam had children, and the re-walk ended in a `nothing`
-                                    interaction without reaching the splitter.  The reference then keeps the stale
-                                    children untouched (System.jl:232-239 sets no cleanup flag); this library drops them
-                                    and raises this flag so the wrapper can fall back to the wrapped System.
-                                    Also raised when a GaussianBeamlet splits BEFORE the end of its stored path: the
-                                    reference then sizes the children (w0, E0) from gauss_parameters(gauss, length(gauss))
-                                    with the stale tail still attached (ThinBeamsplitter.jl:125); this library evaluates
-                                    them at the split point, as a fresh solve would. */
+    BMO_NODE_RETRACE_STALE = 512 /* retrace only, a NOTE (the result is the reference's): retrace_system! acted on stale data here.
+                                    (i) The stored beam had children and the re-walk ended in a `nothing` interaction before
+                                    reaching the splitter: the reference sets no cleanup flag (System.jl:232-239), keeps the
+                                    children and retraces each from its stored first ray — so does this library (the beam then
+                                    has children without BMO_NODE_SPLIT).  (ii) A GaussianBeamlet split BEFORE the end of its
+                                    stored path: the children's w0 / E0 come from gauss_parameters(gauss, length(gauss)) with
+                                    the stale tail still attached (ThinBeamsplitter.jl:125; the tail is cut after the loop,
+                                    System.jl:417-421) — reproduced from the previous solution's segment log.
+                                    (Rounds 1-3 dropped such children / sized them at the split and asked the wrapper to fall back.) */
 };
 
 /* ------------------------------------------------------------------ shapes */

@@ -189,9 +189,12 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             calls += c;
             r.X = X;
             const bool still = old >= 0 && probe && !missed;  // the stored path held at this ray
-            const bool old_kids = still && (prev->node_status[old] & BMO_NODE_SPLIT);
+            const bool old_kids = still && prev->node_first_child[old] >= 0;
+            // the re-walk ends in a `nothing` interaction before the stored splitter: the reference keeps the (stale) children and retraces
+            // each from its stored first ray (System.jl:232-240, 446-458)
+            const bool stale_kids = !survive && old_kids && o.outcome != OUT_SPLIT && X.shape >= 0;
             if (!survive) {
-                if (old_kids && o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
+                if (stale_kids) status |= BMO_NODE_RETRACE_STALE;
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
                 if (o.det_slot >= 0) {
@@ -218,7 +221,7 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
             } else {
                 nodes[r.node].old = -1;
             }
-            if (o.outcome == OUT_SPLIT && !(r.flags & 1) && X.shape >= 0) {
+            if ((o.outcome == OUT_SPLIT || stale_kids) && !(r.flags & 1) && X.shape >= 0) {
                 const int root = nodes[r.node].root;
                 for (int w = 0; w < 2; ++w) {
                     NodeE c2{root, r.node, 1, 0, nd.li, -1, (unsigned long long)w, nd.lambda, {0}};
@@ -226,6 +229,15 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
                     nodes.push_back(c2);
                     Rec q;
                     q.ray = w == 0 ? o.next : o.refl;
+                    if (stale_kids) {  // the stored first ray of the kept child
+                        const int64_t NR = prev->n_records, at = prev->node_first_rec[c2.old];
+                        const double* P = prev->rec;
+                        q.ray.pos = {P[0 * NR + at], P[1 * NR + at], P[2 * NR + at]};
+                        q.ray.dir = {P[3 * NR + at], P[4 * NR + at], P[5 * NR + at]};
+                        q.ray.n = P[6 * NR + at];
+                        if (KIND == BMO_BEAM_POLARIZED)
+                            for (int cc3 = 0; cc3 < 3; ++cc3) q.ray.E0[cc3] = {P[(11 + 2 * cc3) * NR + at], P[(12 + 2 * cc3) * NR + at]};
+                    }
                     q.node = (int)nodes.size() - 1;
                     q.k = 0;
                     q.hobj = q.hshape = -1;
@@ -347,6 +359,22 @@ struct GNode {
     double hit[27];
     int old = -1;
 };
+// the stored rays behind the one a re-walking beamlet is at (bmo_lane.hpp gauss_step_rec `tail`), read from the previous solution's view
+struct EmuTail {
+    const bmo_trace_result_view* prev;
+    int old, k, old_n;
+    int more() const { return (prev && old >= 0) ? old_n - (k + 1) : 0; }
+    double t(int q) const { return prev->rec[(int64_t)7 * prev->n_records + prev->node_first_rec[old] + k + 1 + q]; }
+    RayS ray(int q, int r) const {
+        const int64_t NR = prev->n_records, at = prev->node_first_rec[old] + k + 1 + q;
+        const double* P = prev->rec + (int64_t)11 * r * NR;
+        RayS x;
+        x.pos = {P[0 * NR + at], P[1 * NR + at], P[2 * NR + at]};
+        x.dir = {P[3 * NR + at], P[4 * NR + at], P[5 * NR + at]};
+        x.n = P[6 * NR + at];
+        return x;
+    }
+};
 void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, ResultE& R, bmo_trace_result_view* v,
                const bmo_trace_result_view* prev = nullptr) {
     std::vector<int> oroot;
@@ -443,7 +471,8 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                 ChildCache cc{ccv, 1, 0};
                 double lmv[BMO_LANE_MEM];
                 const LaneMem lm{lmv, 1};
-                gauss_step<2, true>(S, r.g, r.o, c, cc, lm, probe, probe_obj, fresh_allowed, &missed);
+                const EmuTail tail{prev, old, r.k, old_n};
+                gauss_step<2, true, EmuTail>(S, r.g, r.o, c, cc, lm, probe, probe_obj, fresh_allowed, &missed, tail);
                 status = r.o.status;
                 if (r.o.outcome == OUT_CONTINUE) survive = true;
                 else if (r.o.outcome == OUT_SPLIT) status |= BMO_NODE_SPLIT | BMO_NODE_STOPPED;
@@ -451,12 +480,14 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
             }
             calls += c;
             const bool still = old >= 0 && probe && !missed;
-            const bool old_kids = still && (prev->node_status[old] & BMO_NODE_SPLIT);
+            const bool old_kids = still && prev->node_first_child[old] >= 0;
             const bool keep_walking = survive && still && r.k + 1 < old_n;
             if (!keep_walking) nodes[r.node].old = -1;
+            // a `nothing` interaction before the stored splitter: the children are kept and re-walk from their stored first rays (System.jl:393-400)
+            const bool stale_kids = !survive && old_kids && r.o.outcome != OUT_SPLIT && !(r.flags & 1);
             if (!survive) {
-                if (old_kids && r.o.outcome != OUT_SPLIT) status |= BMO_NODE_RETRACE_STALE;
-                if (r.o.outcome == OUT_SPLIT && still && r.k + 1 < old_n) status |= BMO_NODE_RETRACE_STALE;  // the reference sizes the children with the stale tail
+                if (stale_kids) status |= BMO_NODE_RETRACE_STALE;
+                if (r.o.outcome == OUT_SPLIT && still && r.k + 1 < old_n) status |= BMO_NODE_RETRACE_STALE;  // the reference sizes the children with the stale tail (gauss_step_rec `tail`)
                 nodes[r.node].nseg = r.k + 1;
                 nodes[r.node].status = status;
                 if (r.o.det_slot >= 0 && !(r.flags & 1)) nodes[r.node].hit_det = r.o.det_slot;
@@ -488,7 +519,26 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
                 surv.push_back(next(r.o.nc, r.o.nw, r.o.nd, r.node, r.k + 1, pushed ? -1 : r.o.hint_obj, pushed ? -1 : r.o.hint_shape,
                                     (keep_walking || r.k + 2 < opts->r_max) ? 0 : 1, r.o.lenA, r.o.lenB, r.o.oplC, r.o.oplW, r.o.oplD, nodes[r.node]));
             }
-            if (!(r.flags & 1) && r.o.outcome == OUT_SPLIT) {
+            if (stale_kids) {
+                const int oc = prev->node_first_child[old];
+                const int64_t NR = prev->n_records;
+                auto head = [&](int node, int rr) {
+                    const int64_t at = prev->node_first_rec[node];
+                    const double* P = prev->rec + (int64_t)11 * rr * NR;
+                    RayS x;
+                    x.pos = {P[0 * NR + at], P[1 * NR + at], P[2 * NR + at]};
+                    x.dir = {P[3 * NR + at], P[4 * NR + at], P[5 * NR + at]};
+                    x.n = P[6 * NR + at];
+                    return x;
+                };
+                r.o.nc = head(oc, 0), r.o.nw = head(oc, 1), r.o.nd = head(oc, 2);
+                r.o.rc = head(oc + 1, 0), r.o.rw = head(oc + 1, 1), r.o.rd = head(oc + 1, 2);
+                r.o.child_l0 = r.o.lenA + nodes[r.node].l0;
+                r.o.child_w0 = prev->node_aux[4 * oc + 0];
+                r.o.Et = {prev->node_aux[4 * oc + 1], prev->node_aux[4 * oc + 2]};
+                r.o.Er = {prev->node_aux[4 * (oc + 1) + 1], prev->node_aux[4 * (oc + 1) + 2]};
+            }
+            if (!(r.flags & 1) && (r.o.outcome == OUT_SPLIT || stale_kids)) {
                 const int root = nodes[r.node].root;
                 for (int w = 0; w < 2; ++w) {
                     GNode c2{};

@@ -58,7 +58,9 @@ def compare(a, b, rtol=0.0, label=""):
         x, y = getattr(a, name), getattr(b, name)
         assert x.shape == y.shape, (label, name)
         if rtol == 0.0:
-            same = (x == y) | (np.isnan(x) & np.isnan(y))
+            # bit patterns, not values: -0.0 == +0.0 compares equal although Base.min / max and isless tell them apart (NaN payloads aside)
+            xb, yb = np.ascontiguousarray(x, dtype=np.float64).view(np.int64), np.ascontiguousarray(y, dtype=np.float64).view(np.int64)
+            same = (xb == yb) | (np.isnan(x) & np.isnan(y))
             if not same.all():
                 idx = np.argwhere(~same)[:5]
                 raise AssertionError((label, name, "not bit-exact", idx.tolist(), x[~same][:5], y[~same][:5]))

@@ -459,6 +459,52 @@ def test_children_born_in_a_continuation_get_the_full_r_max():
 
 
 @pytest.mark.gpu
+def test_continuation_of_a_beam_list_flushes_detector_rows_root_by_root():
+    """solve_system!(system, [b1, b2, ...]; retrace = false): two splitters in a row send several beams of every tree to ONE
+    detector at different depths; the reference's loop finishes root 1's whole tree before root 2 (System.jl:463-468), so the rows of
+    root 1 — all depths — come before any row of root 2.  Compared with a solve of the same list that never stopped."""
+    mm = 1e-3
+
+    def build(stage):
+        l1 = bmo.SphericalLens(60 * mm, -60 * mm, 4 * mm, 20 * mm, 1.5)
+        bmo.translate3d(l1, [0, 20 * mm, 0])
+        objs = [l1]
+        if stage >= 1:
+            bs1 = bmo.ThinBeamsplitter(30 * mm)
+            bmo.xrotate3d(bs1, math.radians(45))
+            bmo.translate3d(bs1, [0, 60 * mm, 0])
+            bs2 = bmo.ThinBeamsplitter(30 * mm)
+            bmo.xrotate3d(bs2, math.radians(45))
+            bmo.translate3d(bs2, [0, 90 * mm, 0])
+            # folds the arm reflected at bs1 back onto +y so that it meets the detector too, one tree level above bs2's transmitted arm
+            m = bmo.SquarePlanoMirror2D(30 * mm)
+            bmo.xrotate3d(m, math.radians(45))
+            bmo.translate3d(m, [0, 60 * mm, 30 * mm])
+            sd = bmo.Spotdetector(120 * mm)
+            bmo.translate3d(sd, [0, 150 * mm, 10 * mm])
+            objs += [bs1, bs2, m, sd]
+        return bmo.System(objs)
+
+    def beams():
+        return [bmo.Beam(bmo.Ray([dx * mm, 0, 0.3 * dx * mm], [0, 1.0, 0], 1e-6)) for dx in (0.0, 1.0, -2.0)]
+
+    r_max = 10
+    sys_full = build(1)
+    fresh = beams()
+    bmo.solve_system(sys_full, fresh, r_max=r_max)
+    sd_full = sys_full.objects()[-1]
+    assert len(sd_full.data) >= 2 * len(fresh)  # at least two beams of every tree end on the detector
+    again = beams()
+    bmo.solve_system(build(0), again, r_max=r_max)
+    assert all(b.rays[-1].intersection is None for b in again)
+    sys1 = build(1)
+    assert bmo.solve_system(sys1, again, r_max=r_max, retrace=False) is None
+    assert np.array_equal(np.asarray(sys1.objects()[-1].data), np.asarray(sd_full.data))
+    for x in (again, fresh):
+        bmo.release(x)
+
+
+@pytest.mark.gpu
 def test_gauss_prefix_argument_checks():
     """bmo_result_set_gauss_prefix refuses what it cannot mean: a Ray solution, a wrong root count, starts that do not begin at 0 or decrease."""
     import ctypes as C
