@@ -248,6 +248,20 @@ struct StepParams {
     // child in place and pushes the reflected one to the next launch, as long as the launch has pushed fewer than this many; after that a
     // split ends the wave's loop as it always did (block_alloc has room for two records per lane whatever happened before).
     int64_t inwave_cap;
+    // Beam kernels with in-loop splitters: the reflected child of a splitting lane waits in slot j of this chunk (capacity >= cur.count) while
+    // the lane goes on with the transmitted child; when that beam ends — and the wave's loop goes on — the lane takes its kept child up
+    // itself, in the same launch (depth first).  The launch that used to follow for the reflected children alone lasted as long as the
+    // slowest single march among them (SURVEY 8(d)'s config-2 bundle: two grazing marches of ~1 000 evaluations in 10^6 children, 1.3 ms
+    // of a 5.5 ms solve with the device idle); inside the first launch those chains run beside everybody else's work.  A lane keeps ONE
+    // child: a second split while one waits pushes the new reflected child to P.nxt as before; children still waiting when the wave's
+    // loop ends are compacted into P.nxt behind the survivors.  d == nullptr: off.
+    Chunk pend;
+    // Workgroup b of the grid works on tile (grid - 1 - b) instead of tile b: the LAST records of the chunk start first.  The hardware hands
+    // out workgroups in index order, a launch lasts until its slowest wave is done, and the slow waves of a bundle are its edge rays —
+    // grazing exits through lens barrels, marches of 500 - 1 000 evaluations that are one dependent chain of ~1 ms each; a disc source
+    // (BeamGroups.jl:232-243: radius grows with the index) has them at the END of the bundle, and children are queued in the order their
+    // parents finished, the slow ones last again.  Started first, those chains run beside the bulk of the launch instead of behind it.
+    int32_t reverse;
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
 #endif
@@ -288,6 +302,9 @@ struct SlotAlloc {
     unsigned long long surv_base, child_base, node_base;
     unsigned long long m_surv, m_split;
 };
+// PAIRS = false: the second channel counts single records that need no new nodes (reflected children a lane kept for itself and
+// could not get to before its wave's loop ended, StepParams::pend): block layout [survivors of wave 0..3][kept children of wave 0..3].
+template <bool PAIRS = true>
 __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint32_t calls, const StepParams& P, char* scratch, int level = 0) {
     uint32_t* w32 = reinterpret_cast<uint32_t*>(scratch);                         // [0..3] surv, [4..7] split, [8..11] calls, [12..15] level
     unsigned long long* w64 = reinterpret_cast<unsigned long long*>(scratch + 32);  // [0] base, [1] nbase
@@ -314,8 +331,8 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
         }
         if (ml) atomicMax(&P.ctr->max_level[P.parity], (unsigned long long)ml);
         unsigned long long b = 0, nb = 0;
-        if (ts + tp) b = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(ts + 2 * tp));
-        if (tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
+        if (ts + tp) b = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(ts + (PAIRS ? 2 : 1) * tp));
+        if (PAIRS && tp) nb = atomicAdd(&P.ctr->node_count, (unsigned long long)(2 * tp));
         if (tc) atomicAdd(&P.call_shards[(blockIdx.x & 63u) * 16u], (unsigned long long)tc);  // sharded, no return value
         w64[0] = b;
         w64[1] = nb;
@@ -330,11 +347,18 @@ __device__ __forceinline__ SlotAlloc block_alloc(bool survive, bool split, uint3
         ts += w32[w];
     }
     a.surv_base = w64[0] + ps;
-    a.child_base = w64[0] + ts + 2ull * pp;
+    a.child_base = w64[0] + ts + (PAIRS ? 2ull : 1ull) * pp;
     a.node_base = w64[1] + 2ull * pp;
     return a;
 }
 
+// Which tile of the chunk workgroup b of the grid works on (StepParams::reverse): 0 tile b; 1 the tiles from the end; 2 from both ends
+// towards the middle (b even: tile b / 2, b odd: tile grid - 1 - b / 2).
+__device__ __forceinline__ unsigned tile_of_block(int mode, unsigned b, unsigned grid) {
+    if (mode == 1) return grid - 1u - b;
+    if (mode == 2) return (b & 1u) ? grid - 1u - (b >> 1) : (b >> 1);
+    return b;
+}
 #ifndef BMO_MIN_WAVES
 #define BMO_MIN_WAVES 3  /* <= 168 VGPRs.  Round 3: with the scene tables read by scalar loads tracing_step is spill-free at 168 registers and 3 waves/SIMD
                             beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5 (profiles/r03_ab_scalar_scene.txt); 4 (128) still spills in the march */
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         P.ctr->inwave[P.parity ^ 1] = 0;
     }
     using L = Layout<KIND>;
-    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const int64_t gwave = ((int64_t)tile_of_block(P.reverse, blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
     const bool valid = j < m && lane_id() < (1 << P.lane_shift);
@@ -405,6 +429,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     // else is live there) and, in the lane memory, the ray's position and direction where interact's sink left them.  Reading the record
     // back from the chunk cost eleven loads from L2 per level, each at the head of the level's dependency chain.
     int32_t c_node = -1, c_k = 0, c_ho = -1, c_hs = -1, c_fl = 0;
+    int32_t pend_node = -1;  // node of the reflected child this lane keeps for itself in P.pend[j] (StepParams::pend), -1: none
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk_last = wall_clock64();  // time before / in / after tracing_step, summed over the levels
 #endif
@@ -637,18 +662,22 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         // only the reflected one waits for the next launch; otherwise both wait there and the wave's loop ends.
         const unsigned long long m_split = INW ? __ballot(split) : 0ull;
         bool kid_here = false;  // this lane goes on with its transmitted child
+        const bool keep = INW && P.pend.d != nullptr;  // reflected children stay with their lane (StepParams::pend)
         if (!INW) {
             if (go_on) go_on = !__any(split ? 1 : 0);
         } else if (m_split) {
             const int ns = __popcll(m_split);
+            // splitting lanes whose reflected child has to go to P.nxt at once: all of them without `keep`, else those that keep one already
+            const unsigned long long m_push = keep ? (m_split & __ballot(pend_node >= 0)) : m_split;
+            const int np = __popcll(m_push);
             unsigned long long r0 = 0, r1 = 0, r2 = 0;
-            if (go_on) {
+            if (go_on) {  // (every in-loop split counts, kept child or not: the bound also sizes the node table)
                 if (lane_id() == 0) r0 = atomicAdd(&P.ctr->inwave[P.parity], (unsigned long long)ns);
                 r0 = __shfl(r0, 0);
                 if ((int64_t)(r0 + ns) > P.inwave_cap) go_on = false;
             }
             if (lane_id() == 0) {
-                r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? ns : 2 * ns));
+                if (!go_on || np) r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? np : 2 * ns));
                 r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
             }
             r1 = __shfl(r1, 0);
@@ -667,14 +696,21 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     c_ho = c_hs = -1;
                     c_fl = child_flags;
                     lm.m[8 * lm.stride] = opl_next;
-                    write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
+                    if (go_on && keep && pend_node < 0) {  // the reflected child waits for this lane
+                        write_ray(P.pend, jj, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
+                        pend_node = (int32_t)(cn + 1);
+                    } else {
+                        write_next(go_on ? (int64_t)r1 + prefix_rank(m_push) : (int64_t)r1 + 2 * r + 1, o.refl, (int32_t)(cn + 1), 0, -1, -1, child_flags, opl_next);
+                    }
                     kid_here = go_on;
                 } else {
                     atomicAdd(&P.ctr->overflow, 1ull);
                 }
             }
         }
-        if (go_on) go_on = __any((survive || kid_here) ? 1 : 0) != 0;
+        // a lane whose beam ends here takes up the reflected child it kept, if the wave goes on
+        const bool take_kept = INW && valid && alive && !survive && !kid_here && pend_node >= 0;
+        if (go_on) go_on = __any((survive || kid_here || take_kept) ? 1 : 0) != 0;
         if (go_on) {
             // go on in place: the next record of a surviving lane is written to the same slot of the next inner chunk
             const Chunk N = P.inner[b];
@@ -689,6 +725,26 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                     c_hs = hs;
                     c_fl = fl;
                     lm.m[8 * lm.stride] = opl_next;
+                } else if (take_kept) {
+                    // the kept child's first record moves into the log (this level, this slot); its ray goes where a lane that goes on in
+                    // place expects it: position, direction, index and optical path in the lane memory, the header in registers
+                    const int64_t pc = P.pend.cap, nc = N.cap;
+                    BMO_NOUNROLL
+                    for (int q = 0; q < L::ND; ++q) N.d[q * nc + jj] = P.pend.d[q * pc + jj];
+                    c_fl = P.pend.i[I_FLAGS * pc + jj];
+                    N.i[I_NODE * nc + jj] = pend_node;
+                    N.i[I_K * nc + jj] = 0;
+                    N.i[I_HOBJ * nc + jj] = -1;
+                    N.i[I_HSHAPE * nc + jj] = -1;
+                    N.i[I_FLAGS * nc + jj] = c_fl;
+                    lm.put3(0, d3{P.pend.d[0 * pc + jj], P.pend.d[1 * pc + jj], P.pend.d[2 * pc + jj]});
+                    lm.put3(3, d3{P.pend.d[3 * pc + jj], P.pend.d[4 * pc + jj], P.pend.d[5 * pc + jj]});
+                    lm.m[7 * lm.stride] = P.pend.d[6 * pc + jj];
+                    lm.m[8 * lm.stride] = P.pend.d[L::OPL * pc + jj];
+                    c_node = pend_node;
+                    c_k = 0;
+                    c_ho = c_hs = -1;
+                    pend_node = -1;
                 } else if (!kid_here) {
                     N.i[I_NODE * N.cap + jj] = -1;  // no record of this beam at this level
                     alive = false;
@@ -710,12 +766,24 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             atomicAdd(&P.tl[2 * nw + 2], tk2);
         }
 #endif
-        const SlotAlloc al = block_alloc(survive, !INW && split, calls, P, scratch, b);
+        const SlotAlloc al = INW ? block_alloc<false>(survive, pend_node >= 0, calls, P, scratch, b) : block_alloc<true>(survive, split, calls, P, scratch, b);
         if (survive) {  // survivors first
             const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
             int32_t fl, ho, hs;
             next_header(fl, ho, hs);
             write_next(slot, next_ray(), node, k + 1, ho, hs, fl, opl_next);
+        }
+        if (INW && pend_node >= 0) {  // then the reflected children their lanes did not get to: whole records, P.pend -> P.nxt
+            const int64_t slot = (int64_t)al.child_base + prefix_rank(al.m_split);
+            if (slot < ncap) {
+                const int64_t pc = P.pend.cap;
+                BMO_NOUNROLL
+                for (int q = 0; q < L::ND; ++q) P.nxt.d[q * ncap + slot] = P.pend.d[q * pc + jj];
+                BMO_NOUNROLL
+                for (int q = 0; q < NI; ++q) P.nxt.i[q * ncap + slot] = P.pend.i[q * pc + jj];
+            } else {
+                atomicAdd(&P.ctr->overflow, 1ull);
+            }
         }
         if (!INW && split) {  // then 2 children per splitting lane
             const int r = prefix_rank(al.m_split);
@@ -874,7 +942,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
         P.ctr->max_level[P.parity ^ 1] = 0;
         P.ctr->inwave[P.parity ^ 1] = 0;
     }
-    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const int64_t gwave = ((int64_t)tile_of_block(P.reverse, blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
     const bool valid = j < m && lane_id() < (1 << P.lane_shift);
@@ -1971,6 +2039,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (const char* e = getenv(GAUSS ? "BMO_FUSE_GAUSS" : "BMO_FUSE")) fuse_max = std::max(1, std::min(fuse_max, atoi(e)));
     DevBuf gstage;
     int64_t gstage_cap = 0;
+    DevBuf pend_buf;  // StepParams::pend
+    int64_t pend_cap = 0;
+    static const bool keep_kids_on = !(getenv("BMO_KEEP_KIDS") && atoi(getenv("BMO_KEEP_KIDS")) == 0);
     double keep_ratio = 1.0;  // share of the previous launch's beams that went on (the fuse-count rule of round 2: launches above BMO_INWAVE_MAX only)
     while (cur.count > 0) {
         const int64_t m = cur.count;
@@ -2000,7 +2071,15 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         // the next launch's chunk first, then the in-place levels: the levels no wave reaches go back to the arena after the launch
         // (in-loop beam splitters of the Beam kernels: room for up to m reflected children more, StepParams::inwave_cap)
         const int64_t inwave_cap = (has_split && (kern_inw || GAUSS) && n_fuse > 1 && tail) ? m : 0;
-        if ((rc = new_chunk((has_split ? 2 * m : m) + inwave_cap, nxt))) return rc;
+        // (kept reflected children, StepParams::pend: a lane can end its wave's loop with a kept child AND two fresh ones — one record more per lane)
+        const bool keep_kids = inwave_cap > 0 && !GAUSS && keep_kids_on;
+        if ((rc = new_chunk((has_split ? 2 * m : m) + inwave_cap + (keep_kids ? m : 0), nxt))) return rc;
+        if (keep_kids && m > pend_cap) {  // one buffer for the whole solve (the previous launch has completed: its block goes back at once)
+            PoolHold::Now at_once;
+            pend_buf.release();
+            pend_cap = (m + 1) & ~(int64_t)1;
+            if ((rc = pend_buf.alloc((size_t)pend_cap * rec_bytes))) return rc;
+        }
         uint8_t* wl = nullptr;
         if (keep_log && n_fuse > 1) {
             auto b = std::make_unique<DevBuf>();
@@ -2061,6 +2140,17 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.wave_last = wl;
         P.lane_shift = lane_shift;
         P.inwave_cap = inwave_cap;
+        P.pend = Chunk{nullptr, nullptr, 0, 0};
+        if (keep_kids) {
+            P.pend.d = static_cast<double*>(pend_buf.p);
+            P.pend.i = reinterpret_cast<int32_t*>(static_cast<char*>(pend_buf.p) + (size_t)pend_cap * (size_t)L::ND * 8);
+            P.pend.cap = pend_cap;
+            P.pend.count = m;
+        }
+        {
+            static const int reverse_order = getenv("BMO_REVERSE") ? atoi(getenv("BMO_REVERSE")) : 1;
+            P.reverse = reverse_order;
+        }
 #if defined(BMO_DEV_TIMELINE)  // developer builds, BMO_TIMELINE=1: how many waves are at work over the course of every launch
         DevBuf tl_buf;
         P.tl = nullptr;
@@ -2113,6 +2203,21 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
             fprintf(stderr, "[bmo] timeline step %d: %zu waves, span %.3f ms; mean waves at work per 1/%d of the span:\n ", steps, nw, span / 1e5, NB);
             for (int q = 0; q < NB; ++q) fprintf(stderr, " %.0f", busy[q]);
             fprintf(stderr, "\n");
+            {  // the waves that end last: where in the grid they sit, when they started
+                std::vector<size_t> idx(nw);
+                for (size_t w = 0; w < nw; ++w) idx[w] = w;
+                const size_t top = std::min<size_t>(nw, 12);
+                std::partial_sort(idx.begin(), idx.begin() + (long)top, idx.end(), [&](size_t a, size_t b2) { return t[2 * a + 1] > t[2 * b2 + 1]; });
+                fprintf(stderr, "[bmo] timeline step %d: last waves to end (wave of the grid: start .. end in ms):", steps);
+                for (size_t q = 0; q < top; ++q) fprintf(stderr, "  %zu: %.3f .. %.3f", idx[q], (double)(t[2 * idx[q]] - t0) / 1e5, (double)(t[2 * idx[q] + 1] - t0) / 1e5);
+                fprintf(stderr, "\n");
+                std::vector<double> dur(nw);
+                for (size_t w = 0; w < nw; ++w) dur[w] = (double)(t[2 * w + 1] - t[2 * w]) / 1e5;
+                std::vector<double> srt = dur;
+                std::sort(srt.begin(), srt.end());
+                fprintf(stderr, "[bmo] timeline step %d: wave durations ms p50 %.3f p90 %.3f p99 %.3f p99.9 %.3f max %.3f\n", steps, srt[nw / 2], srt[nw * 9 / 10], srt[nw * 99 / 100],
+                        srt[std::min(nw - 1, nw * 999 / 1000)], srt[nw - 1]);
+            }
         }
 #endif
         const unsigned long long produced = h_ctr.next_count[steps & 1];

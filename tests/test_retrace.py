@@ -476,10 +476,11 @@ def test_continuation_of_a_beam_list_flushes_detector_rows_root_by_root():
             bs2 = bmo.ThinBeamsplitter(30 * mm)
             bmo.xrotate3d(bs2, math.radians(45))
             bmo.translate3d(bs2, [0, 90 * mm, 0])
-            # folds the arm reflected at bs1 back onto +y so that it meets the detector too, one tree level above bs2's transmitted arm
+            # bs1 reflects +y into -z; this mirror folds that arm back onto +y (past bs2) so that it meets the detector too, one tree
+            # level above bs2's transmitted arm
             m = bmo.SquarePlanoMirror2D(30 * mm)
             bmo.xrotate3d(m, math.radians(45))
-            bmo.translate3d(m, [0, 60 * mm, 30 * mm])
+            bmo.translate3d(m, [0, 60 * mm, -30 * mm])
             sd = bmo.Spotdetector(120 * mm)
             bmo.translate3d(sd, [0, 150 * mm, 10 * mm])
             objs += [bs1, bs2, m, sd]
