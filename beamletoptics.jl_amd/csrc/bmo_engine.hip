@@ -26,6 +26,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -248,6 +249,7 @@ struct StepParams {
     // child in place and pushes the reflected one to the next launch, as long as the launch has pushed fewer than this many; after that a
     // split ends the wave's loop as it always did (block_alloc has room for two records per lane whatever happened before).
     int64_t inwave_cap;
+    int64_t nodes0;  // beams (nodes) in existence when the launch starts
     // Beam kernels with in-loop splitters: the reflected child of a splitting lane waits in slot j of this chunk (capacity >= cur.count) while
     // the lane goes on with the transmitted child; when that beam ends — and the wave's loop goes on — the lane takes its kept child up
     // itself, in the same launch (depth first).  The launch that used to follow for the reflected children alone lasted as long as the
@@ -256,12 +258,19 @@ struct StepParams {
     // child: a second split while one waits pushes the new reflected child to P.nxt as before; children still waiting when the wave's
     // loop ends are compacted into P.nxt behind the survivors.  d == nullptr: off.
     Chunk pend;
+    double* gkeep;  // GaussianBeamlet kernels: the kept reflected child of lane j, [24][gstage_cap]: its rays as in gstage, then l0, oplC, flags
     // Workgroup b of the grid works on tile (grid - 1 - b) instead of tile b: the LAST records of the chunk start first.  The hardware hands
     // out workgroups in index order, a launch lasts until its slowest wave is done, and the slow waves of a bundle are its edge rays —
     // grazing exits through lens barrels, marches of 500 - 1 000 evaluations that are one dependent chain of ~1 ms each; a disc source
     // (BeamGroups.jl:232-243: radius grows with the index) has them at the END of the bundle, and children are queued in the order their
     // parents finished, the slow ones last again.  Started first, those chains run beside the bulk of the launch instead of behind it.
     int32_t reverse;
+    // Longest-processing-time-first, from feedback (first launch of a solve over a batch that has been solved before): workgroup b works on
+    // tile tile_order[b], the tiles sorted by the time they took in the previous solve of this batch, slowest first — the hardware hands out
+    // workgroups in index order and a launch ends when its slowest wave does.  tile_cost[tile]: this launch's time of every tile
+    // (s_memrealtime ticks), written for the next solve.  Both nullptr: `reverse` decides.  Results do not depend on any of it.
+    const int32_t* tile_order;
+    uint32_t* tile_cost;
 #if defined(BMO_DEV_TIMELINE)
     unsigned long long* tl;  // developer builds: [2 * wave] start, [2 * wave + 1] end of every wave (wall_clock64, 100 MHz)
 #endif
@@ -386,7 +395,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         P.ctr->inwave[P.parity ^ 1] = 0;
     }
     using L = Layout<KIND>;
-    const int64_t gwave = ((int64_t)tile_of_block(P.reverse, blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const unsigned tile = P.tile_order ? (unsigned)P.tile_order[blockIdx.x] : tile_of_block(P.reverse, blockIdx.x, gridDim.x);
+    if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64();  // start stamp; turned into the tile's time at the end
+    const int64_t gwave = ((int64_t)tile * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
     const bool valid = j < m && lane_id() < (1 << P.lane_shift);
@@ -670,18 +681,16 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
             // splitting lanes whose reflected child has to go to P.nxt at once: all of them without `keep`, else those that keep one already
             const unsigned long long m_push = keep ? (m_split & __ballot(pend_node >= 0)) : m_split;
             const int np = __popcll(m_push);
-            unsigned long long r0 = 0, r1 = 0, r2 = 0;
-            if (go_on) {  // (every in-loop split counts, kept child or not: the bound also sizes the node table)
-                if (lane_id() == 0) r0 = atomicAdd(&P.ctr->inwave[P.parity], (unsigned long long)ns);
-                r0 = __shfl(r0, 0);
-                if ((int64_t)(r0 + ns) > P.inwave_cap) go_on = false;
-            }
-            if (lane_id() == 0) {
-                if (!go_on || np) r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? np : 2 * ns));
-                r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
-            }
-            r1 = __shfl(r1, 0);
+            unsigned long long r1 = 0, r2 = 0;
+            // the node pairs first: their running count is also the number of in-loop splits of this launch so far (every node a launch of
+            // this kernel makes is made here), which the launch's room bounds — one returning atomic instead of two in a row
+            if (lane_id() == 0) r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
             r2 = __shfl(r2, 0);
+            if (go_on && (int64_t)((r2 - (unsigned long long)P.nodes0) / 2ull + ns) > P.inwave_cap) go_on = false;  // (kept child or not: the bound also sizes the node table)
+            if (!go_on || np) {
+                if (lane_id() == 0) r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? np : 2 * ns));
+                r1 = __shfl(r1, 0);
+            }
             if (split) {
                 const int r = prefix_rank(m_split);
                 const int64_t cn = (int64_t)r2 + 2 * r;
@@ -785,6 +794,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 atomicAdd(&P.ctr->overflow, 1ull);
             }
         }
+        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64() - P.tile_cost[tile];  // (behind block_alloc's barrier: all four waves are done)
         if (!INW && split) {  // then 2 children per splitting lane
             const int r = prefix_rank(al.m_split);
             const int64_t slot = (int64_t)al.child_base + 2 * r;
@@ -942,13 +952,17 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
         P.ctr->max_level[P.parity ^ 1] = 0;
         P.ctr->inwave[P.parity ^ 1] = 0;
     }
-    const int64_t gwave = ((int64_t)tile_of_block(P.reverse, blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
+    const unsigned tile = P.tile_order ? (unsigned)P.tile_order[blockIdx.x] : tile_of_block(P.reverse, blockIdx.x, gridDim.x);
+    if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64();  // start stamp; turned into the tile's time at the end
+    const int64_t gwave = ((int64_t)tile * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
     const bool valid = j < m && lane_id() < (1 << P.lane_shift);
     bool alive = valid;
     uint32_t calls = 0;
     const int64_t ncap = P.nxt.cap;
+    int32_t pend_node = -1;  // node of the reflected child this lane keeps for itself in P.gkeep (StepParams::pend), -1: none
+    const bool keep = P.gkeep != nullptr;
     // accumulators and header of a record whose rays are in place already
     auto write_tail = [&](const Chunk& T, int64_t slot, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,
                           double oplW, double oplD) {
@@ -1087,18 +1101,16 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
         bool kid_here = false;
         if (m_split) {
             const int ns = __popcll(m_split);
-            unsigned long long r0 = 0, r1 = 0, r2 = 0;
-            if (go_on) {
-                if (lane_id() == 0) r0 = atomicAdd(&P.ctr->inwave[P.parity], (unsigned long long)ns);
-                r0 = __shfl(r0, 0);
-                if ((int64_t)(r0 + ns) > P.inwave_cap) go_on = false;
-            }
-            if (lane_id() == 0) {
-                r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? ns : 2 * ns));
-                r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);
-            }
-            r1 = __shfl(r1, 0);
+            const unsigned long long m_push = keep ? (m_split & __ballot(pend_node >= 0)) : m_split;  // reflected children that go to P.nxt at once
+            const int np = __popcll(m_push);
+            unsigned long long r1 = 0, r2 = 0;
+            if (lane_id() == 0) r2 = atomicAdd(&P.ctr->node_count, 2ull * ns);  // (also counts the launch's in-loop splits: see step_kernel)
             r2 = __shfl(r2, 0);
+            if (go_on && (int64_t)((r2 - (unsigned long long)P.nodes0) / 2ull + ns) > P.inwave_cap) go_on = false;
+            if (!go_on || np) {
+                if (lane_id() == 0) r1 = atomicAdd(&P.ctr->next_count[P.parity], (unsigned long long)(go_on ? np : 2 * ns));
+                r1 = __shfl(r1, 0);
+            }
             if (split) {
                 const int r = prefix_rank(m_split);
                 const int64_t cn = (int64_t)r2 + 2 * r;
@@ -1132,21 +1144,39 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
                     // children: chief inherits the parent chain (parent! Gaussian.jl:113-117); waist/div beams have no parent
                     if (go_on) write_tail(N, j, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);  // (its rays are in place)
                     else write_next((int64_t)r1 + 2 * r, N.d, N.cap, 11, (int32_t)cn, 0, -1, -1, fl, 0.0, o.child_l0, o.oplC, 0.0, 0.0);
-                    write_next(go_on ? (int64_t)r1 + r : (int64_t)r1 + 2 * r + 1, P.gstage, P.gstage_cap, 7, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0, o.child_l0, o.oplC,
-                               0.0, 0.0);
+                    if (go_on && keep && pend_node < 0) {  // the reflected child waits for this lane (the staging planes serve the next split)
+                        const int64_t gc = P.gstage_cap;
+                        BMO_NOUNROLL
+                        for (int q = 0; q < 21; ++q) P.gkeep[q * gc + j] = P.gstage[q * gc + j];
+                        P.gkeep[21 * gc + j] = o.child_l0;
+                        P.gkeep[22 * gc + j] = o.oplC;
+                        P.gkeep[23 * gc + j] = (double)fl;
+                        pend_node = (int32_t)(cn + 1);
+                    } else {
+                        write_next(go_on ? (int64_t)r1 + prefix_rank(m_push) : (int64_t)r1 + 2 * r + 1, P.gstage, P.gstage_cap, 7, (int32_t)(cn + 1), 0, -1, -1, fl, 0.0,
+                                   o.child_l0, o.oplC, 0.0, 0.0);
+                    }
                     kid_here = go_on;
                 } else {
                     atomicAdd(&P.ctr->overflow, 1ull);
                 }
             }
         }
-        if (go_on) go_on = __any((survive || kid_here) ? 1 : 0) != 0;
+        const bool take_kept = valid && alive && !survive && !kid_here && pend_node >= 0;  // this lane's beamlet ends here: it takes up the child it kept
+        if (go_on) go_on = __any((survive || kid_here || take_kept) ? 1 : 0) != 0;
         if (go_on) {
             if (valid) {
                 if (alive && survive) {
                     int32_t fl, ho, hs;
                     next_header(fl, ho, hs);
                     write_tail(N, j, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
+                } else if (take_kept) {
+                    const int64_t gc = P.gstage_cap, nc = N.cap;
+                    BMO_NOUNROLL
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 7; ++c) N.d[(11 * r + c) * nc + j] = P.gkeep[(int64_t)(7 * r + c) * gc + j];
+                    write_tail(N, j, pend_node, 0, -1, -1, (int32_t)P.gkeep[23 * gc + j], 0.0, P.gkeep[21 * gc + j], P.gkeep[22 * gc + j], 0.0, 0.0);
+                    pend_node = -1;
                 } else if (!kid_here) {
                     N.i[I_NODE * N.cap + j] = -1;  // no record of this beamlet at this level
                     alive = false;
@@ -1157,13 +1187,19 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
         }
         // ---- last fused bounce of this wave
         if (P.wave_last && lane_id() == 0) P.wave_last[gwave] = (uint8_t)b;
-        const SlotAlloc al = block_alloc(survive, false, calls, P, scratch, b);
+        const SlotAlloc al = block_alloc<false>(survive, pend_node >= 0, calls, P, scratch, b);
         if (survive) {
             const int64_t slot = (int64_t)al.surv_base + prefix_rank(al.m_surv);
             int32_t fl, ho, hs;
             next_header(fl, ho, hs);
             write_next(slot, N.d, N.cap, 11, node, k + 1, ho, hs, fl, o.lenA, o.lenB, o.oplC, o.oplW, o.oplD);
         }
+        if (pend_node >= 0) {  // the reflected children their lanes did not get to
+            const int64_t gc = P.gstage_cap;
+            write_next((int64_t)al.child_base + prefix_rank(al.m_split), P.gkeep, gc, 7, pend_node, 0, -1, -1, (int32_t)P.gkeep[23 * gc + j], 0.0, P.gkeep[21 * gc + j],
+                       P.gkeep[22 * gc + j], 0.0, 0.0);
+        }
+        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64() - P.tile_cost[tile];
         return;
     }
 }
@@ -1186,6 +1222,92 @@ __global__ void root_key_kernel(const char* __restrict__ blob, BlobHeader hdr, c
     }
     keys[j] = mask;
     ids[j] = (int32_t)j;
+}
+
+// Coherence order of the root rays (round 4).  A wave works on one shape at a time and a level of a wave lasts as long as its slowest
+// lane, so the 64 rays of a wave should be NEIGHBOURS IN RAY SPACE — same elements, similar marches, ending together.  Bundle order does not
+// give that: a disc source numbers its rays along a spiral (BeamGroups.jl:232-243: equal radius, every azimuth) and draws directions at random.
+// A ray's line is described by the two points where it enters and leaves the scene's bounding sphere (the two-sphere parametrisation of a
+// light field: position and direction weigh in with the leverage they have over the scene, no scale to choose); the rays are sorted by a
+// Morton code over those six coordinates, scaled to the bundle's own extent.  In front of the code sits the ray's distance from the bundle's
+// middle in that space, farthest first: the marginal rays are the ones that graze barrels and rims — marches of 500 - 1 000 evaluations,
+// one dependent chain of ~1 ms each — and a launch ends when its slowest wave does, so they have to START first (the hardware hands out
+// workgroups in index order).  Beam nodes keep the bundle's numbering: result order, detector order and retrace do not see any of this.
+__global__ void root_chord_kernel(const double* __restrict__ planes, int64_t n, double cx, double cy, double cz, double R, double* __restrict__ chord) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double px = planes[0 * n + j], py = planes[1 * n + j], pz = planes[2 * n + j], dx = planes[3 * n + j], dy = planes[4 * n + j], dz = planes[5 * n + j];
+    const double ox = cx - px, oy = cy - py, oz = cz - pz;
+    const double dd = dx * dx + dy * dy + dz * dz, b = ox * dx + oy * dy + oz * dz, cc = ox * ox + oy * oy + oz * oz - R * R;
+    const double disc = b * b - dd * cc;
+    double e[6] = {cx, cy, cz, cx, cy, cz};  // (a line that misses the sphere meets nothing: it sorts to the middle, where it disturbs nobody)
+    if (dd > 0.0 && disc >= 0.0) {
+        const double sq = sqrt(disc), t0 = (b - sq) / dd, t1 = (b + sq) / dd;
+        e[0] = px + t0 * dx, e[1] = py + t0 * dy, e[2] = pz + t0 * dz;
+        e[3] = px + t1 * dx, e[4] = py + t1 * dy, e[5] = pz + t1 * dz;
+    }
+    for (int q = 0; q < 6; ++q) chord[q * n + j] = (e[q] == e[q]) ? e[q] : (q % 3 == 0 ? cx : (q % 3 == 1 ? cy : cz));
+}
+// lim[0..5] minima, lim[6..11] maxima of the six chord coordinates over the bundle
+__global__ void root_order_key_kernel(const double* __restrict__ chord, int64_t n, const double* __restrict__ lim, unsigned long long* __restrict__ keys, int32_t* __restrict__ ids) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    unsigned long long key = 0;
+    double far2 = 0.0;
+    for (int g = 0; g < 2; ++g) {  // entry points, exit points: one scale per point set (isotropic)
+        double hw = 0.0, mid[3];
+        for (int a = 0; a < 3; ++a) {
+            const double lo = lim[3 * g + a], hi = lim[6 + 3 * g + a];
+            mid[a] = 0.5 * (lo + hi);
+            hw = fmax(hw, 0.5 * (hi - lo));
+        }
+        double r2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double u = hw > 0.0 ? (chord[(3 * g + a) * n + j] - mid[a]) / hw : 0.0;  // [-1, 1]
+            r2 += u * u;
+            int q = (int)floor(u * 512.0 + 512.0);
+            q = q < 0 ? 0 : (q > 1023 ? 1023 : q);
+            unsigned long long v = (unsigned long long)q, sp = 0;
+            for (int bit = 0; bit < 10; ++bit) sp |= ((v >> bit) & 1ull) << (6 * bit);
+            key |= sp << (3 * g + a);
+        }
+        far2 = fmax(far2, r2);
+    }
+    // 16 coarse rings around the middle of the bundle in front of the code, outermost first (measured: the ragged config-2 bundle 9.0 ms
+    // with them, 9.7 ms without; finer rings cost the multi-train scene 10 %): marginal rays — the ones that graze barrels — sit together
+    // and start first when no feedback orders the tiles yet
+    int ring = (int)(sqrt(far2) * 12.0);
+    ring = ring > 15 ? 15 : ring;
+    keys[j] = ((unsigned long long)(15 - ring) << 60) | key;
+    ids[j] = (int32_t)j;
+}
+// Is the bundle's OWN numbering coherent already?  A disc source numbers its rays along a spiral (BeamGroups.jl:232-243): neighbours in the
+// bundle sit at the same distance from the bundle's axis at every azimuth, and in a system that is close to rotationally symmetric about
+// that axis such rays share their path exactly — 64 of them make a better wave than any patch of the Morton code (1/30 of the bundle wide in
+// radius): SURVEY 8(d)'s collimated disc runs 40 % slower in Morton order.  Measure: the mean jump, from one ray to the next in bundle order,
+// of the entry point's distance from the middle of the bundle's entry points (in units of the bundle's half width).  sum[0] += the jumps.
+__global__ void root_ring_jump_kernel(const double* __restrict__ chord, int64_t n, const double* __restrict__ lim, double* __restrict__ sum) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double hw = 0.0, mid[3];
+    for (int a = 0; a < 3; ++a) {
+        mid[a] = 0.5 * (lim[a] + lim[6 + a]);
+        hw = fmax(hw, 0.5 * (lim[6 + a] - lim[a]));
+    }
+    double jump = 0.0;
+    if (j + 1 < n && hw > 0.0) {
+        double r[2];
+        for (int q = 0; q < 2; ++q) {
+            double r2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double u = (chord[a * n + j + q] - mid[a]) / hw;
+                r2 += u * u;
+            }
+            r[q] = sqrt(r2);
+        }
+        jump = fabs(r[1] - r[0]);
+    }
+    for (int off = 32; off > 0; off >>= 1) jump += __shfl_down(jump, off);
+    if ((threadIdx.x & 63) == 0 && jump != 0.0) atomicAdd(sum, jump);
 }
 
 // Slot s of the first chunk holds root ray perm[s] (perm == nullptr: ray s); `slot_planes` are the batch's planes in slot order (the
@@ -1662,6 +1784,7 @@ struct HostBuf {
 struct bmo_scene {
     std::vector<char> blob;
     BlobHeader hdr;
+    double bound[4] = {0, 0, 0, -1};  // a sphere around the bounding spheres of all candidates (centre, radius; radius < 0: none) — root_chord_kernel
     std::vector<std::pair<int, std::unique_ptr<DevBuf>>> dev;  // per-device copy of the blob
     std::mutex dev_mu;  // the handle is shared between host threads (include/bmo.h "Threading"): the lazy per-device upload is the one mutation
     const char* device_blob(int device, int& rc) {
@@ -1689,6 +1812,10 @@ struct bmo_device_batch {
     DevBuf planes, li;
     DevBuf perm;    // slot -> root ray, roots binned by coherence key (empty: bundle order is kept; root_key_kernel)
     DevBuf binned;  // the planes in slot order (only with perm)
+    // feedback for the next solve of this batch (StepParams::tile_order): time of every tile of the first launch, the tiles sorted by it
+    DevBuf tile_cost, tile_order, lpt_ids, lpt_keys, lpt_tmp;
+    int64_t tile_n = 0;
+    bool cost_valid = false;
 };
 
 struct bmo_trace_result {
@@ -2039,6 +2166,7 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     if (const char* e = getenv(GAUSS ? "BMO_FUSE_GAUSS" : "BMO_FUSE")) fuse_max = std::max(1, std::min(fuse_max, atoi(e)));
     DevBuf gstage;
     int64_t gstage_cap = 0;
+    DevBuf gkeep;     // StepParams::gkeep
     DevBuf pend_buf;  // StepParams::pend
     int64_t pend_cap = 0;
     static const bool keep_kids_on = !(getenv("BMO_KEEP_KIDS") && atoi(getenv("BMO_KEEP_KIDS")) == 0);
@@ -2072,9 +2200,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         // (in-loop beam splitters of the Beam kernels: room for up to m reflected children more, StepParams::inwave_cap)
         const int64_t inwave_cap = (has_split && (kern_inw || GAUSS) && n_fuse > 1 && tail) ? m : 0;
         // (kept reflected children, StepParams::pend: a lane can end its wave's loop with a kept child AND two fresh ones — one record more per lane)
-        const bool keep_kids = inwave_cap > 0 && !GAUSS && keep_kids_on;
+        const bool keep_kids = inwave_cap > 0 && keep_kids_on;
         if ((rc = new_chunk((has_split ? 2 * m : m) + inwave_cap + (keep_kids ? m : 0), nxt))) return rc;
-        if (keep_kids && m > pend_cap) {  // one buffer for the whole solve (the previous launch has completed: its block goes back at once)
+        if (keep_kids && !GAUSS && m > pend_cap) {  // one buffer for the whole solve (the previous launch has completed: its block goes back at once)
             PoolHold::Now at_once;
             pend_buf.release();
             pend_cap = (m + 1) & ~(int64_t)1;
@@ -2117,8 +2245,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if (KIND == BMO_BEAM_GAUSSIAN && m > gstage_cap) {
             PoolHold::Now at_once;
             gstage.release();
+            gkeep.release();
             gstage_cap = ((m + m / 8 + 1) & ~(int64_t)1);
-            if ((rc = gstage.alloc((size_t)gstage_cap * 21 * 8))) return rc;
+            if ((rc = gstage.alloc((size_t)gstage_cap * 21 * 8)) || (rc = gkeep.alloc((size_t)gstage_cap * 24 * 8))) return rc;
         }
         StepParams P;
         P.gstage = (double*)gstage.p;
@@ -2140,16 +2269,49 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         P.wave_last = wl;
         P.lane_shift = lane_shift;
         P.inwave_cap = inwave_cap;
+        P.nodes0 = n_nodes;
         P.pend = Chunk{nullptr, nullptr, 0, 0};
-        if (keep_kids) {
+        P.gkeep = (GAUSS && keep_kids) ? (double*)gkeep.p : nullptr;
+        if (keep_kids && !GAUSS) {
             P.pend.d = static_cast<double*>(pend_buf.p);
             P.pend.i = reinterpret_cast<int32_t*>(static_cast<char*>(pend_buf.p) + (size_t)pend_cap * (size_t)L::ND * 8);
             P.pend.cap = pend_cap;
             P.pend.count = m;
         }
+        P.tile_order = nullptr;
+        P.tile_cost = nullptr;
         {
-            static const int reverse_order = getenv("BMO_REVERSE") ? atoi(getenv("BMO_REVERSE")) : 1;
-            P.reverse = reverse_order;
+            static const bool lpt_on = !(getenv("BMO_LPT") && atoi(getenv("BMO_LPT")) == 0);
+            if (lpt_on && steps == 0 && lane_shift == 6 && n_blocks >= 64) {
+                if (batch->tile_n != (int64_t)n_blocks) {
+                    PoolHold::Now at_once;
+                    batch->cost_valid = false;
+                    batch->tile_n = 0;
+                    batch->tile_cost.release(), batch->tile_order.release(), batch->lpt_ids.release(), batch->lpt_keys.release(), batch->lpt_tmp.release();
+                    size_t tb = 0;
+                    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                                                         (int)n_blocks, 0, 32, stream));
+                    if ((rc = batch->tile_cost.alloc((size_t)n_blocks * 4)) || (rc = batch->tile_order.alloc((size_t)n_blocks * 4)) ||
+                        (rc = batch->lpt_ids.alloc((size_t)n_blocks * 4)) || (rc = batch->lpt_keys.alloc((size_t)n_blocks * 4)) || (rc = batch->lpt_tmp.alloc(std::max<size_t>(tb, 16))))
+                        return rc;
+                    hipLaunchKernelGGL(iota_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, (int32_t*)batch->lpt_ids.p, (int64_t)n_blocks);
+                    batch->tile_n = (int64_t)n_blocks;
+                }
+                if (batch->cost_valid) {
+                    size_t tb = batch->lpt_tmp.bytes;
+                    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(batch->lpt_tmp.p, tb, (const uint32_t*)batch->tile_cost.p, (uint32_t*)batch->lpt_keys.p,
+                                                                         (const int32_t*)batch->lpt_ids.p, (int32_t*)batch->tile_order.p, (int)n_blocks, 0, 32, stream));
+                    P.tile_order = (const int32_t*)batch->tile_order.p;
+                }
+                P.tile_cost = (uint32_t*)batch->tile_cost.p;
+                batch->cost_valid = true;  // (after this launch)
+            }
+        }
+        {
+            // without feedback (StepParams::tile_order) a launch starts from the END of its chunk: a disc source has its marginal rays there,
+            // children and survivors are queued in the order their parents got there — the slow ones last (StepParams::reverse)
+            static const int reverse_order = getenv("BMO_REVERSE") ? atoi(getenv("BMO_REVERSE")) : -1;
+            P.reverse = reverse_order >= 0 ? reverse_order : 1;
         }
 #if defined(BMO_DEV_TIMELINE)  // developer builds, BMO_TIMELINE=1: how many waves are at work over the course of every launch
         DevBuf tl_buf;
@@ -2652,6 +2814,27 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
     fill_candidates(d->objects, d->n_objects, d->shapes, reinterpret_cast<Cand*>(sc->blob.data() + h.off_cands));  // trace_all's flat slot list
+    {  // the scene's bounding sphere: centre of the box around the candidates' spheres, radius to the farthest of them
+        const Cand* cd = reinterpret_cast<const Cand*>(sc->blob.data() + h.off_cands);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        int nb = 0;
+        for (int i = 0; i < h.n_cands; ++i) {
+            if (!(cd[i].R >= 0.0) || !std::isfinite(cd[i].R)) continue;
+            const double c[3] = {cd[i].cx, cd[i].cy, cd[i].cz};
+            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], c[a] - cd[i].R), hi[a] = std::max(hi[a], c[a] + cd[i].R);
+            ++nb;
+        }
+        if (nb) {
+            double R = 0.0;
+            for (int a = 0; a < 3; ++a) sc->bound[a] = 0.5 * (lo[a] + hi[a]);
+            for (int i = 0; i < h.n_cands; ++i) {
+                if (!(cd[i].R >= 0.0) || !std::isfinite(cd[i].R)) continue;
+                const double dx = cd[i].cx - sc->bound[0], dy = cd[i].cy - sc->bound[1], dz = cd[i].cz - sc->bound[2];
+                R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + cd[i].R);
+            }
+            sc->bound[3] = R;
+        }
+    }
     sc->hdr = h;
     *out = sc.release();
     return BMO_OK;
@@ -2693,7 +2876,57 @@ int bmo_batch_upload(bmo_scene* scene, const bmo_ray_batch* in, int32_t device, 
     }
     // Roots are binned by coherence key once, here (a stable sort: bundle order within a key).  A bundle whose rays all have one key —
     // a single disc source aimed at one train — keeps its order and costs nothing later; BMO_NO_BINNING=1 switches the step off.
-    if (in->n >= 4096 && scene->hdr.n_cands > 0 && !getenv("BMO_NO_BINNING")) {
+    // BMO_ROOT_ORDER = chord (default: root_order_key_kernel) | mask (round 3's candidate-set keys, below) | none
+    const char* order_env = getenv("BMO_ROOT_ORDER");
+    std::string root_order = order_env ? order_env : (getenv("BMO_NO_BINNING") ? "none" : "auto");
+    if (in->n >= 4096 && scene->hdr.n_cands > 0 && scene->bound[3] > 0.0 && (root_order == "chord" || root_order == "auto")) {
+        const int64_t n = in->n;
+        DevBuf chord, lim, keys, keys_out, ids, tmp;
+        if ((rc = chord.alloc((size_t)n * 6 * 8)) || (rc = lim.alloc(13 * 8)) || (rc = keys.alloc((size_t)n * 8)) || (rc = keys_out.alloc((size_t)n * 8)) ||
+            (rc = ids.alloc((size_t)n * 4)) || (rc = b->perm.alloc((size_t)n * 4)))
+            return rc;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(root_chord_kernel, dim3(nb), dim3(256), 0, nullptr, (const double*)b->planes.p, n, scene->bound[0], scene->bound[1], scene->bound[2],
+                           scene->bound[3], (double*)chord.p);
+        size_t tb = 0, tb2 = 0;
+        HIP_TRY(hipcub::DeviceReduce::Min(nullptr, tb, (const double*)chord.p, (double*)lim.p, (int)n, nullptr));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, (const unsigned long long*)keys.p, (unsigned long long*)keys_out.p, (const int32_t*)ids.p,
+                                                   (int32_t*)b->perm.p, (int)n, 0, 64, nullptr));
+        if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
+        for (int q = 0; q < 6; ++q) {
+            size_t t1 = tmp.bytes;
+            HIP_TRY(hipcub::DeviceReduce::Min(tmp.p, t1, (const double*)chord.p + (size_t)q * n, (double*)lim.p + q, (int)n, nullptr));
+            t1 = tmp.bytes;
+            HIP_TRY(hipcub::DeviceReduce::Max(tmp.p, t1, (const double*)chord.p + (size_t)q * n, (double*)lim.p + 6 + q, (int)n, nullptr));
+        }
+        bool own_order = false;  // keep the bundle's own numbering (+ the candidate-set bins below)
+        if (root_order == "auto") {
+            double jump = 0.0;
+            HIP_TRY(hipMemsetAsync((double*)lim.p + 12, 0, 8, nullptr));
+            hipLaunchKernelGGL(root_ring_jump_kernel, dim3(nb), dim3(256), 0, nullptr, (const double*)chord.p, n, (const double*)lim.p, (double*)lim.p + 12);
+            HIP_TRY(hipMemcpy(&jump, (const double*)lim.p + 12, 8, hipMemcpyDeviceToHost));
+            own_order = jump / (double)n < 0.01;  // (a spiral: ~1e-6; positions or directions drawn at random: ~0.3)
+            DBG("root order: mean ring jump %.3g -> %s", jump / (double)n, own_order ? "the bundle's own order" : "Morton order of the chords");
+        }
+        if (own_order) {
+            b->perm.release();
+            root_order = "mask";
+        } else {
+        root_order = "chord";
+        hipLaunchKernelGGL(root_order_key_kernel, dim3(nb), dim3(256), 0, nullptr, (const double*)chord.p, n, (const double*)lim.p, (unsigned long long*)keys.p,
+                           (int32_t*)ids.p);
+        size_t t2 = tmp.bytes;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t2, (const unsigned long long*)keys.p, (unsigned long long*)keys_out.p, (const int32_t*)ids.p,
+                                                   (int32_t*)b->perm.p, (int)n, 0, 64, nullptr));
+        if ((rc = b->binned.alloc((size_t)n * in->n_planes * 8))) return rc;
+        hipLaunchKernelGGL(bin_planes_kernel, dim3(nb), dim3(256), 0, nullptr, (const double*)b->planes.p, (const int32_t*)b->perm.p, n, (int)in->n_planes,
+                           (double*)b->binned.p);
+        HIP_TRY(hipDeviceSynchronize());  // the temporaries go back to the pool
+        HIP_TRY(hipGetLastError());
+        }
+    }
+    if (root_order == "auto") root_order = "mask";  // (no bound to take chords through)
+    if (in->n >= 4096 && scene->hdr.n_cands > 0 && root_order == "mask") {
         const char* dblob = scene->device_blob(device, rc);
         if (rc) return rc;
         const int64_t n = in->n;

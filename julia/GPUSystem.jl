@@ -83,7 +83,7 @@ end
 
 # ------------------------------------------------------------------------------------------------ the container
 """
-    GPUSystem(inner::AbstractSystem; device = 0, max_beams = 0)
+    GPUSystem(inner::AbstractSystem; device = 0, max_beams = 0, segments = :all)
 
 An [`AbstractSystem`](@ref) whose `solve_system!` runs on the MI355X engine.  `inner` stays the source of truth for
 `objects(system)` and is what unsupported cases fall back to.  `max_beams > 0` stops a solve whose beam tree outgrows it (a
@@ -93,10 +93,15 @@ mutable struct GPUSystem{S <: AbstractSystem} <: AbstractSystem
     inner::S
     device::Int32
     max_beams::Int32
+    # :all  — every ray of every beam comes back (`bmo_result_view`: what solve_system! leaves behind, 2.3 GB over PCIe for config 2);
+    # :last — only last(rays(beam)) of every beam, the beam tree and the detectors' data (`bmo_result_view_select`, 0.5 GB): each rebuilt
+    #         beam then holds ONE ray, its last; length(rays(beam)) is NOT the reference's — for spot diagrams / PSFs of large bundles
+    segments::Symbol
     # beams (or the beam group) solved before => bmo_trace_result* kept resident in HBM so that the next solve can retrace it
     solved::IdDict{Any, Ptr{Cvoid}}
-    function GPUSystem(inner::S; device::Integer = 0, max_beams::Integer = 0) where {S <: AbstractSystem}
-        sys = new{S}(inner, Int32(device), Int32(max_beams), IdDict{Any, Ptr{Cvoid}}())
+    function GPUSystem(inner::S; device::Integer = 0, max_beams::Integer = 0, segments::Symbol = :all) where {S <: AbstractSystem}
+        segments in (:all, :last) || throw(ArgumentError("segments must be :all or :last"))
+        sys = new{S}(inner, Int32(device), Int32(max_beams), segments, IdDict{Any, Ptr{Cvoid}}())
         finalizer(release!, sys)
         return sys
     end
@@ -120,6 +125,26 @@ struct BmoError <: Exception
     code::Int
     msg::String
 end
+"""
+The library this process loaded, checked once (the twin of `abi._check_source_hash` in beamletoptics.jl_amd/abi.py): its ABI version has to
+be the one this file binds; the hashes of the sources and of the compiler flags it was built from (`bmo_source_hash`,
+`bmo_build_flags_hash`: bit-level parity with `solve_system!` needs `-ffp-contract=off` & co.) are compared with `ENV["BMO_SOURCE_HASH"]` /
+`ENV["BMO_FLAGS_HASH"]` when a deployment pins them, and kept in `LIB_INFO` for bug reports.
+"""
+const LIB_INFO = Ref{Union{Nothing, NamedTuple{(:abi, :source_hash, :flags_hash), Tuple{Int, String, String}}}}(nothing)
+function check_library()
+    LIB_INFO[] === nothing || return LIB_INFO[]
+    abi = Int(ccall((:bmo_version, LIBBMO), Cint, ()))
+    abi == BMO_ABI_VERSION || error("GPUSystem: $(LIBBMO) speaks ABI version $abi, this file binds version $(BMO_ABI_VERSION)")
+    src = unsafe_string(ccall((:bmo_source_hash, LIBBMO), Cstring, ()))
+    flg = unsafe_string(ccall((:bmo_build_flags_hash, LIBBMO), Cstring, ()))
+    want_src, want_flg = get(ENV, "BMO_SOURCE_HASH", ""), get(ENV, "BMO_FLAGS_HASH", "")
+    isempty(want_src) || want_src == src || error("GPUSystem: $(LIBBMO) was built from other sources (source hash $src, expected $want_src)")
+    isempty(want_flg) || want_flg == flg || error("GPUSystem: $(LIBBMO) was built with other compiler flags (flags hash $flg, expected $want_flg)")
+    LIB_INFO[] = (abi = abi, source_hash = src, flags_hash = flg)
+    return LIB_INFO[]
+end
+
 function check(rc::Cint)
     rc == BMO_OK && return nothing
     msg = unsafe_string(ccall((:bmo_last_error, LIBBMO), Cstring, ()))
@@ -431,6 +456,7 @@ struct HostView                                   # Julia arrays over the librar
     rec::Matrix{Float64}                          # [n_records, rec_planes]: plane p is column p
     det_count::Vector{Int64}; det_offset::Vector{Int64}
     det::Matrix{Float64}                          # [9, total hits]
+    det_node::Vector{Int32}                       # node (result order) that made each hit
 end
 function HostView(v::BmoResultView)
     nn, nr, nd = Int(v.n_nodes), Int(v.n_records), Int(v.n_detectors)
@@ -439,7 +465,7 @@ function HostView(v::BmoResultView)
     tot = Int(sum(cnt))
     return HostView(v, w(v.node_root, nn), w(v.node_parent, nn), w(v.node_first_rec, nn), w(v.node_nseg, nn), w(v.node_status, nn),
                     w(v.node_aux, 4, nn), w(v.rec_obj, nr), w(v.rec_shape, nr), w(v.rec, nr, Int(v.rec_planes)), cnt, w(v.det_offset, nd),
-                    w(v.det_data, 9, tot))
+                    w(v.det_data, 9, tot), w(v.det_node, tot))
 end
 
 # ray k (1-based record index r) of one (sub-)beam; `base` = first plane of that ray inside the record (0, 11, 22)
@@ -464,12 +490,13 @@ Rebuilds the beam trees from the result tables.  Nodes arrive in reference order
 children, transmitted child before reflected child), so one forward pass links everything.  Root nodes are the caller's own beam
 objects (mutated in place, like `solve_system!` does); child beams are created here.
 """
-function rebuild_beams!(roots::Vector, kind::Int32, hv::HostView, leaves, shape_refs)
+function rebuild_beams!(roots::Vector, kind::Int32, hv::HostView, leaves, shape_refs; last_only::Bool = false)
     nn = length(hv.root)
     nodes = Vector{Any}(undef, nn)
     for i in 1:nn
         par = hv.parent[i]
-        f, n = Int(hv.first_rec[i]), Int(hv.nseg[i])
+        # (a BMO_VIEW_LAST_SEGMENT view holds ONE record per beam, node_first_rec[i] = i, while node_nseg stays the true ray count)
+        f, n = Int(hv.first_rec[i]), last_only ? 1 : Int(hv.nseg[i])
         recs = (f + 1):(f + n)
         if kind == BEAM_GAUSSIAN
             w0, E0, λ = hv.aux[1, i], complex(hv.aux[2, i], hv.aux[3, i]), hv.aux[4, i]
@@ -520,19 +547,26 @@ function raise_status(hv::HostView)
 end
 
 "Appends the detector records of this solve in the reference's push! order (detectors are not reset, as in the reference)."
-function push_detector_data!(tb::SceneTables, hv::HostView, res::Ptr{Cvoid})
+function push_detector_data!(tb::SceneTables, hv::HostView, res::Ptr{Cvoid}; defer = nothing, nodes = nothing, opl0 = nothing)
+    # `defer` (an IdDict beam => records, with `nodes` = the beams of the result in node order): Spot / PSF records are not pushed but
+    # left with the beam that made them, for a caller that merges several solves into the reference's order (trace_open_leaves!);
+    # `opl0[root + 1]`: optical path a continued Ray / PolarizedRay beam had behind it, added to its PSF records
+    keep!(h, rec, det) = push!(get!(() -> Any[], defer, nodes[hv.det_node[h] + 1]), (det, rec))
     for (slot0, det) in enumerate(tb.detectors)
         cnt, off = Int(hv.det_count[slot0]), Int(hv.det_offset[slot0])
         if det isa Spotdetector
             T = typeof(det.hw)
             for h in (off + 1):(off + cnt)
-                push!(det, Point2{T}(hv.det[1, h], hv.det[2, h]))                                                   # Spotdetector.jl:50-61
+                rec = Point2{T}(hv.det[1, h], hv.det[2, h])
+                defer === nothing ? push!(det, rec) : keep!(h, rec, det)                                            # Spotdetector.jl:50-61
             end
         elseif det isa PSFDetector
             T = eltype(vertices(shape(det)))
             for h in (off + 1):(off + cnt)
                 D = view(hv.det, :, h)
-                push!(det, PSFData{T}(Point3{T}(D[1], D[2], D[3]), Point3{T}(D[4], D[5], D[6]), D[7], D[8], D[9]))  # PSFDetector.jl:77-89
+                opl = opl0 === nothing ? D[7] : D[7] + opl0[hv.root[hv.det_node[h] + 1] + 1]
+                rec = PSFData{T}(Point3{T}(D[1], D[2], D[3]), Point3{T}(D[4], D[5], D[6]), opl, D[8], D[9])
+                defer === nothing ? push!(det, rec) : keep!(h, rec, det)                                            # PSFDetector.jl:77-89
             end
         elseif det isa Photodetector && cnt > 0
             # Photodetector.jl:69-107: field[i, j] += electric_field(gauss, r, z) * sqrt(proj), evaluated on the GPU from the segment
@@ -556,7 +590,7 @@ end
 
 src/System.jl:444-468 on the GPU.  Fresh beams are traced (`bmo_trace`); beams this system solved before are retraced
 (`bmo_retrace`, src/System.jl:188-255 and :326-428) against the solution kept in HBM.  `retrace = false` on solved beams only
-re-traces leaves whose last ray has no intersection (src/System.jl:470-475); that rare mode is left to the wrapped system.
+traces leaves on whose last ray has no intersection (src/System.jl:449-458, :470-475): `trace_open_leaves!` below, on the GPU.
 """
 function solve_system!(sys::GPUSystem, bg::AbstractBeamGroup; r_max::Int = 100, retrace::Bool = true)
     return gpu_solve!(sys, bg, collect(beams(bg)); r_max, retrace)
@@ -567,9 +601,18 @@ end
 
 function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Bool)
     isempty(roots) && return nothing
+    check_library()
     prev = get(sys.solved, key, C_NULL)
     fallback() = (forget!(sys, key); solve_system!(sys.inner, key; r_max, retrace))
-    prev != C_NULL && !retrace && return fallback()
+    if prev != C_NULL && !retrace   # solved beams, not re-walked: only the open leaves are traced on (System.jl:449-458, :470-475)
+        sys.segments === :all || return fallback()   # (their open last rays are all a :last solution holds, but not the lengths in front of them)
+        try
+            return trace_open_leaves!(sys, key, roots; r_max)
+        catch e
+            e isa BmoUnsupported || rethrow()
+            return fallback()
+        end
+    end
     local tb, ntab, kind
     try
         kind = beam_kind(first(roots))
@@ -596,20 +639,20 @@ function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Boo
             end
         end
         try
-            check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+            if sys.segments === :all
+                check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+            else   # beam tree, last(rays(beam)) of every beam and the detectors' data: no segment log over PCIe
+                check(ccall((:bmo_result_view_select, LIBBMO), Cint, (Ptr{Cvoid}, UInt32, Ref{BmoResultView}), res[], VIEW_HITS | VIEW_LAST_SEGMENT, view))
+            end
         catch
             ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])   # the solution stays in HBM otherwise (ADVICE r02)
             rethrow()
         end
         hv = HostView(view[])
-        if any(s -> s & NODE_RETRACE_STALE != 0, hv.status)
-            # the one place the engine deviates from retrace_system! (DESIGN.md §6 f1): let the reference handle this solve
-            ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
-            return fallback()
-        end
+        # (NODE_RETRACE_STALE is a note since round 4: kept stale children and stale-tail splits are what retrace_system! does, DESIGN.md §6 f1)
         try
             raise_status(hv)
-            rebuild_beams!(roots, kind, hv, leaves, tb.shape_refs)
+            rebuild_beams!(roots, kind, hv, leaves, tb.shape_refs; last_only = sys.segments === :last)
             push_detector_data!(tb, hv, res[])
         catch e
             ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
@@ -627,6 +670,168 @@ function gpu_solve!(sys::GPUSystem, key, roots::Vector; r_max::Int, retrace::Boo
     end
     return nothing
 end
+# ------------------------------------------------------------------------------------------------ retrace = false on solved beams
+nrays(b::Beam) = length(rays(b))
+nrays(g::GaussianBeamlet) = length(rays(g.chief))
+ray_length(r) = intersection(r) === nothing ? Inf : length(intersection(r))
+
+"""
+`solve_system!(...; retrace = false)` on beams solved before (src/System.jl:449-458, solve_leaf! :470-475): nothing is re-walked; every beam
+of the trees whose LAST ray has no intersection is traced on from that ray, without a hint, up to `r_max` rays in the beam; everything else
+stays as it is.  The open last rays are traced as one fresh batch per distinct remaining length and spliced back (the twin of
+`_trace_open_leaves` in beamletoptics.jl_amd/system.py, where every step of this is tested on the GPU).  A batch applies ONE ray limit —
+what the beams it continues have left — while the reference gives every child born in the continuation the full `r_max`: children that
+ran into the batch's limit are open beams themselves and are continued by the next pass.  Detector records are appended at the end, in the
+order the reference's loop makes them: root by root (System.jl:463-468), breadth first (:446-458).
+"""
+function trace_open_leaves!(sys::GPUSystem, key, roots::Vector; r_max::Int)
+    open = Any[]
+    for root in roots
+        queue = Any[root]
+        while !isempty(queue)
+            b = popfirst!(queue)
+            append!(queue, children(b))
+            _last_beam_intersection(b) === nothing && nrays(b) < r_max && push!(open, b)
+        end
+    end
+    pending = IdDict{Any, Vector{Any}}()
+    while !isempty(open)
+        open = continue_open_beams!(sys, open, pending; r_max)
+    end
+    for root in roots   # one breadth-first walk per root: root 1's whole tree before root 2
+        queue = Any[root]
+        while !isempty(queue)
+            b = popfirst!(queue)
+            append!(queue, children(b))
+            for (det, rec) in get(pending, b, ())
+                push!(det, rec)
+            end
+        end
+    end
+    forget!(sys, key)   # the resident solution no longer describes these beams: the next solve traces them afresh
+    return nothing
+end
+
+"One pass of `trace_open_leaves!`; returns the beams born in it that ran into the pass's ray limit below `r_max`."
+function continue_open_beams!(sys::GPUSystem, open_beams::Vector, pending; r_max::Int)
+    again = Any[]
+    by_left = Dict{Int, Vector{Any}}()
+    for b in open_beams
+        push!(get!(() -> Any[], by_left, r_max - nrays(b) + 1), b)
+    end
+    for left in sort!(collect(keys(by_left)))
+        group = by_left[left]
+        kind = beam_kind(first(group))
+        gaussian = kind == BEAM_GAUSSIAN
+        # heads: fresh beams that hold the open last ray(s) only
+        heads = Any[]
+        for b in group
+            if gaussian
+                T = typeof(wavelength(b))
+                sub(part) = Beam{T, Ray{T}}([last(rays(part))], nothing, Vector{Beam{T, Ray{T}}}())
+                push!(heads, GaussianBeamlet(sub(b.chief), sub(b.waist), sub(b.divergence), wavelength(b), beam_waist(b), electric_field(b)))
+            else
+                push!(heads, typeof(b)([last(rays(b))], nothing, typeof(b.children)()))
+            end
+        end
+        λs = sort(unique(Float64[head_wavelength(h) for h in heads]))
+        leaves = collect(objects(sys.inner))
+        tb, ntab = flatten_scene(leaves, λs)
+        planes, li = pack_first_rays(heads, kind, λs)
+        n = length(heads)
+        np = PLANES_IN[kind + 1]
+        if gaussian
+            # the lengths the beamlets have accumulated up to their open rays (include/bmo.h "31 planes": lenA, lenB, l0, oplC, oplW, oplD),
+            # folded exactly as a solve that had never stopped would have folded them (bmo_lane.hpp GaussIn)
+            acc = zeros(Float64, 6 * n)
+            for (i, b) in enumerate(group)
+                l0 = b.parent === nothing ? 0.0 : Float64(length(b.parent))
+                len_a, len_b = 0.0, l0
+                opl_c = b.chief.parent === nothing ? 0.0 : Float64(optical_path_length(b.chief.parent))
+                for r in rays(b.chief)[1:(end - 1)]
+                    len_a += ray_length(r); len_b += ray_length(r); opl_c += ray_length(r) * refractive_index(r)
+                end
+                opl_w = sum(Float64[ray_length(r) * refractive_index(r) for r in rays(b.waist)[1:(end - 1)]]; init = 0.0)
+                opl_d = sum(Float64[ray_length(r) * refractive_index(r) for r in rays(b.divergence)[1:(end - 1)]]; init = 0.0)
+                for (q, v) in enumerate((len_a, len_b, l0, opl_c, opl_w, opl_d))
+                    acc[(q - 1) * n + i] = v
+                end
+            end
+            planes = vcat(planes, acc)
+            np += 6
+        end
+        scene, res, view = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL), Ref{BmoResultView}()
+        GC.@preserve tb ntab planes li begin
+            desc = scene_desc(tb, ntab)
+            check(ccall((:bmo_scene_create, LIBBMO), Cint, (Ref{BmoSceneDesc}, Ref{Ptr{Cvoid}}), desc, scene))
+            try
+                batch = BmoRayBatch(n, kind, np, pointer(planes), pointer(li))
+                opts = BmoTraceOpts(left, sys.device, 1, sys.max_beams)
+                check(ccall((:bmo_trace, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoRayBatch}, Ref{BmoTraceOpts}, Ref{Ptr{Cvoid}}), scene[], batch, opts, res))
+            finally
+                ccall((:bmo_scene_destroy, LIBBMO), Cint, (Ptr{Cvoid},), scene[])
+            end
+        end
+        try
+            if gaussian && any(o -> o isa Photodetector, leaves)
+                # the field of a beamlet on a Photodetector is a function of ALL its rays (point_on_beam, length, optical_path_length:
+                # Beam.jl:125-205); the continuation holds only those from the open ray on, the ones in front of it go along as a prefix
+                starts, cols, opl_par = Int32[0], Float64[], Float64[]
+                nseg = 0
+                for b in group
+                    for k in 1:(nrays(b) - 1)
+                        for part in (b.chief, b.waist, b.divergence)
+                            r = rays(part)[k]
+                            append!(cols, (position(r)..., direction(r)..., refractive_index(r), ray_length(r)))
+                        end
+                        nseg += 1
+                    end
+                    push!(starts, Int32(nseg))
+                    push!(opl_par, b.chief.parent === nothing ? 0.0 : Float64(optical_path_length(b.chief.parent)))
+                end
+                segs = nseg == 0 ? Float64[] : vec(permutedims(reshape(cols, 24, nseg)))   # [24][total]: plane-major
+                GC.@preserve starts segs opl_par check(ccall((:bmo_result_set_gauss_prefix, LIBBMO), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), res[], n, starts, segs, opl_par))
+            end
+            check(ccall((:bmo_result_view, LIBBMO), Cint, (Ptr{Cvoid}, Ref{BmoResultView}), res[], view))
+            hv = HostView(view[])
+            raise_status(hv)
+            nodes = rebuild_beams!(heads, kind, hv, leaves, tb.shape_refs)
+            # optical path each continued Ray / PolarizedRay beam had behind it (parents included) up to the start of its open ray: what PSF
+            # records of the continuation lack (a continued beamlet brings its path lengths along in the batch)
+            opl0 = gaussian ? nothing : Float64[(b.parent === nothing ? 0.0 : Float64(optical_path_length(b.parent))) +
+                                                sum(Float64[ray_length(r) * refractive_index(r) for r in rays(b)[1:(end - 1)]]; init = 0.0) for b in group]
+            push_detector_data!(tb, hv, res[]; defer = pending, nodes = nodes, opl0 = opl0)
+            for (b, h) in zip(group, heads)   # splice: the open ray (now with its intersection, if any) and what followed it
+                if gaussian
+                    for (part, hp) in ((b.chief, h.chief), (b.waist, h.waist), (b.divergence, h.divergence))
+                        pop!(rays(part)); append!(rays(part), rays(hp))
+                    end
+                    for c in children(h)
+                        parent!(c, b)               # also links chief.parent (Gaussian.jl:113-117)
+                    end
+                else
+                    pop!(rays(b)); append!(rays(b), rays(h))
+                    for c in children(h)
+                        parent!(c, b)
+                    end
+                end
+                b.children = children(h)
+                haskey(pending, h) && append!(get!(() -> Any[], pending, b), pop!(pending, h))
+            end
+            if left < r_max
+                for i in (length(group) + 1):length(nodes)   # beams born in this pass
+                    nd = nodes[i]
+                    (hv.status[i] & NODE_RMAX) != 0 && _last_beam_intersection(nd) === nothing && nrays(nd) < r_max && push!(again, nd)
+                end
+            end
+        finally
+            ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), res[])
+        end
+    end
+    return again
+end
+
 function forget!(sys::GPUSystem, key)
     h = pop!(sys.solved, key, C_NULL)
     h != C_NULL && ccall((:bmo_result_free, LIBBMO), Cint, (Ptr{Cvoid},), h)

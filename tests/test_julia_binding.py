@@ -42,7 +42,9 @@ def test_every_ccall_binds_a_declared_symbol_with_its_arity():
     decl = _c_functions()
     calls = re.findall(r"ccall\(\(:(bmo_[a-z_]+), LIBBMO\),\s*(\w+),\s*\(", JL)
     assert {"bmo_scene_create", "bmo_trace", "bmo_retrace", "bmo_result_view", "bmo_result_free", "bmo_scene_destroy", "bmo_last_error",
-            "bmo_photodetector_field", "bmo_psf_intensity"} <= {c[0] for c in calls}
+            "bmo_photodetector_field", "bmo_psf_intensity",
+            # round 4: the library check at first use, the selective view, the retrace = false continuation with its beamlet prefix
+            "bmo_version", "bmo_source_hash", "bmo_build_flags_hash", "bmo_result_view_select", "bmo_result_set_gauss_prefix"} <= {c[0] for c in calls}
     for m in re.finditer(r"ccall\(\(:(bmo_[a-z_]+), LIBBMO\),\s*(\w+),\s*\(", JL):
         name = m.group(1)
         assert name in decl, name
@@ -163,3 +165,17 @@ def test_every_shape_and_object_kind_of_the_header_is_flattened_or_refused():
               "Spotdetector", "PSFDetector", "Photodetector", "IntersectableObject", "NonInteractableObject", "PolarizationFilter", "AbstractObject"):
         assert re.search(r"object_record\(tb, o::%s\)" % t, JL), t
     assert JL.count("throw(BmoUnsupported(") >= 5
+
+
+def test_julia_file_keeps_up_with_its_python_twin():
+    """Round 4: what system.py does on the device, the Julia file does too instead of falling back to the wrapped System —
+    the retrace = false continuation (System.jl:449-475) and retraces flagged BMO_NODE_RETRACE_STALE (a note now, not a deviation)."""
+    assert "function trace_open_leaves!" in JL and "function continue_open_beams!" in JL
+    body = JL[JL.index("function gpu_solve!"):JL.index("function trace_open_leaves!")]
+    assert "trace_open_leaves!(sys, key, roots; r_max)" in body
+    assert "NODE_RETRACE_STALE != 0" not in body  # no fallback on the flag any more
+    assert "check_library()" in body
+    # the continuation hands over the six accumulated lengths of a beamlet (bmo.h "31 planes") and one ray limit per pass
+    cont = JL[JL.index("function continue_open_beams!"):JL.index("function forget!")]
+    assert "np += 6" in cont and "BmoTraceOpts(left, sys.device, 1, sys.max_beams)" in cont
+    assert int(re.search(r"#define BMO_PLANES_GAUSSIAN_CONTINUED (\d+)", HDR).group(1)) == bmo.abi.PLANES_IN[2] + 6
