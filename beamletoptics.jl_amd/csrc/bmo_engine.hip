@@ -79,7 +79,8 @@ struct BlobHeader {
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
     uint32_t has_asphere, off_cands;
-    int32_t n_cands, has_meniscus, pad[2];
+    int32_t n_cands, has_meniscus, n_groups;
+    uint32_t off_groups;
 };
 
 // `h`: the blob's header; the kernels read it from their arguments (scalar loads the compiler may repeat instead of holding the
@@ -95,6 +96,8 @@ __host__ __device__ inline SceneView view_of(CharPtr blob, const BlobHeader* h) 
     S.coefs = (CDouble*)(blob + h->off_coefs);
     S.cands = (const BMO_KONST Cand*)(blob + h->off_cands);
     S.n_cands = h->n_cands;
+    S.groups = (const BMO_KONST CandGroup*)(blob + h->off_groups);
+    S.n_groups = h->n_groups;
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -2792,6 +2795,8 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     h.off_cands = (uint32_t)off;
     h.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, nullptr);
     off = al(off + sizeof(Cand) * (size_t)(std::max(1, h.n_cands) + 3));  // (+ 3 zero entries: the collection of tracing_step reads four per trip)
+    h.off_groups = (uint32_t)off;
+    off = al(off + sizeof(CandGroup) * (size_t)std::max(1, h.n_cands));  // (at most one group per entry)
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -2814,6 +2819,20 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
     fill_candidates(d->objects, d->n_objects, d->shapes, reinterpret_cast<Cand*>(sc->blob.data() + h.off_cands));  // trace_all's flat slot list
+    {  // the second level of the candidate table; BMO_CAND_GROUPS=0 switches it off (tests: shortcuts-on == shortcuts-off == oracle)
+        const char* e = getenv("BMO_CAND_GROUPS");
+        int ng = 0;
+        if (!(e && atoi(e) == 0) && h.n_cands >= 16)
+            ng = fill_cand_groups(reinterpret_cast<const Cand*>(sc->blob.data() + h.off_cands), h.n_cands, reinterpret_cast<CandGroup*>(sc->blob.data() + h.off_groups));
+        h.n_groups = ng > 1 ? ng : 0;
+        std::memcpy(sc->blob.data(), &h, sizeof h);
+        if (dbg_on()) {
+            const CandGroup* G = reinterpret_cast<const CandGroup*>(sc->blob.data() + h.off_groups);
+            for (int g = 0; g < h.n_groups; ++g)
+                DBG("candidate group %d: entries %d..%d  box x %.4g..%.4g  y %.4g..%.4g  z %.4g..%.4g", g, G[g].first, G[g].first + G[g].count - 1, G[g].lo[0], G[g].hi[0],
+                    G[g].lo[1], G[g].hi[1], G[g].lo[2], G[g].hi[2]);
+        }
+    }
     {  // the scene's bounding sphere: centre of the box around the candidates' spheres, radius to the farthest of them
         const Cand* cd = reinterpret_cast<const Cand*>(sc->blob.data() + h.off_cands);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
