@@ -79,8 +79,7 @@ struct BlobHeader {
     uint32_t off_objects, off_shapes, off_children, off_tris, off_ntable, total;
     uint32_t has_splitter, off_coefs;
     uint32_t has_asphere, off_cands;
-    int32_t n_cands, has_meniscus, n_groups;
-    uint32_t off_groups;
+    int32_t n_cands, has_meniscus, pad[2];
 };
 
 // `h`: the blob's header; the kernels read it from their arguments (scalar loads the compiler may repeat instead of holding the
@@ -96,8 +95,6 @@ __host__ __device__ inline SceneView view_of(CharPtr blob, const BlobHeader* h) 
     S.coefs = (CDouble*)(blob + h->off_coefs);
     S.cands = (const BMO_KONST Cand*)(blob + h->off_cands);
     S.n_cands = h->n_cands;
-    S.groups = (const BMO_KONST CandGroup*)(blob + h->off_groups);
-    S.n_groups = h->n_groups;
     S.n_objects = h->n_objects;
     S.n_lambda = h->n_lambda;
     S.eps_srf = h->eps_srf;
@@ -399,7 +396,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
     }
     using L = Layout<KIND>;
     const unsigned tile = P.tile_order ? (unsigned)P.tile_order[blockIdx.x] : tile_of_block(P.reverse, blockIdx.x, gridDim.x);
+#if !defined(BMO_NO_TILE_COST)
     if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64();  // start stamp; turned into the tile's time at the end
+#endif
     const int64_t gwave = ((int64_t)tile * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
@@ -676,7 +675,11 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
         // only the reflected one waits for the next launch; otherwise both wait there and the wave's loop ends.
         const unsigned long long m_split = INW ? __ballot(split) : 0ull;
         bool kid_here = false;  // this lane goes on with its transmitted child
+#if defined(BMO_NO_KEEP)
+        const bool keep = false;
+#else
         const bool keep = INW && P.pend.d != nullptr;  // reflected children stay with their lane (StepParams::pend)
+#endif
         if (!INW) {
             if (go_on) go_on = !__any(split ? 1 : 0);
         } else if (m_split) {
@@ -797,7 +800,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepPara
                 atomicAdd(&P.ctr->overflow, 1ull);
             }
         }
+#if !defined(BMO_NO_TILE_COST)
         if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64() - P.tile_cost[tile];  // (behind block_alloc's barrier: all four waves are done)
+#endif
         if (!INW && split) {  // then 2 children per splitting lane
             const int r = prefix_rank(al.m_split);
             const int64_t slot = (int64_t)al.child_base + 2 * r;
@@ -956,7 +961,9 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
         P.ctr->inwave[P.parity ^ 1] = 0;
     }
     const unsigned tile = P.tile_order ? (unsigned)P.tile_order[blockIdx.x] : tile_of_block(P.reverse, blockIdx.x, gridDim.x);
+#if !defined(BMO_NO_TILE_COST)
     if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)wall_clock64();  // start stamp; turned into the tile's time at the end
+#endif
     const int64_t gwave = ((int64_t)tile * blockDim.x + threadIdx.x) >> 6;  // wave of the grid
     const int64_t j = (gwave << P.lane_shift) + lane_id();
     const int64_t m = P.cur.count;
@@ -965,7 +972,13 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
     uint32_t calls = 0;
     const int64_t ncap = P.nxt.cap;
     int32_t pend_node = -1;  // node of the reflected child this lane keeps for itself in P.gkeep (StepParams::pend), -1: none
+    // (measured, profiles/r04_ab_scheduling.txt: in this kernel the kept child costs more registers than the saved launch gives back —
+    //  228 B of scratch per lane instead of 196, config 3 10.56 ms per solve against 10.34 — so it is compiled in with -DBMO_GAUSS_KEEP only)
+#if defined(BMO_GAUSS_KEEP)
     const bool keep = P.gkeep != nullptr;
+#else
+    const bool keep = false;
+#endif
     // accumulators and header of a record whose rays are in place already
     auto write_tail = [&](const Chunk& T, int64_t slot, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,
                           double oplW, double oplD) {
@@ -2140,6 +2153,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         if (!prev && ext == 0) kern = &step_kernel<BMO_BEAM_RAY, 0, false, false>, kern_inw = &step_kernel<BMO_BEAM_RAY, 0, false, true>;
     }
     if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY> is compiled in");
+#elif defined(BMO_DEV_GAUSS_ONLY)  // developer build: the fresh GaussianBeamlet kernel of the plain-shapes level only
+    if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
+        if (!prev && ext == 0) kern = &step_kernel_gauss<0, false>;
+    }
+    if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel_gauss<0, false> is compiled in");
 #else
     if constexpr (KIND == BMO_BEAM_GAUSSIAN) {
         if (prev) kern = ext == 2 ? &step_kernel_gauss<2, true> : (ext == 1 ? &step_kernel_gauss<1, true> : &step_kernel_gauss<0, true>);
@@ -2795,8 +2813,6 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     h.off_cands = (uint32_t)off;
     h.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, nullptr);
     off = al(off + sizeof(Cand) * (size_t)(std::max(1, h.n_cands) + 3));  // (+ 3 zero entries: the collection of tracing_step reads four per trip)
-    h.off_groups = (uint32_t)off;
-    off = al(off + sizeof(CandGroup) * (size_t)std::max(1, h.n_cands));  // (at most one group per entry)
     h.total = (uint32_t)off;
     sc->blob.assign(off, 0);
     std::memcpy(sc->blob.data(), &h, sizeof h);
@@ -2819,20 +2835,6 @@ int bmo_scene_create(const bmo_scene_desc* d, bmo_scene** out) {
     if (d->n_media) std::memcpy(sc->blob.data() + h.off_ntable, d->n_table, 8 * (size_t)d->n_media * (size_t)d->n_lambda);
     if (d->n_coefs > 0) std::memcpy(sc->blob.data() + h.off_coefs, d->coefs, 8 * (size_t)d->n_coefs);
     fill_candidates(d->objects, d->n_objects, d->shapes, reinterpret_cast<Cand*>(sc->blob.data() + h.off_cands));  // trace_all's flat slot list
-    {  // the second level of the candidate table; BMO_CAND_GROUPS=0 switches it off (tests: shortcuts-on == shortcuts-off == oracle)
-        const char* e = getenv("BMO_CAND_GROUPS");
-        int ng = 0;
-        if (!(e && atoi(e) == 0) && h.n_cands >= 16)
-            ng = fill_cand_groups(reinterpret_cast<const Cand*>(sc->blob.data() + h.off_cands), h.n_cands, reinterpret_cast<CandGroup*>(sc->blob.data() + h.off_groups));
-        h.n_groups = ng > 1 ? ng : 0;
-        std::memcpy(sc->blob.data(), &h, sizeof h);
-        if (dbg_on()) {
-            const CandGroup* G = reinterpret_cast<const CandGroup*>(sc->blob.data() + h.off_groups);
-            for (int g = 0; g < h.n_groups; ++g)
-                DBG("candidate group %d: entries %d..%d  box x %.4g..%.4g  y %.4g..%.4g  z %.4g..%.4g", g, G[g].first, G[g].first + G[g].count - 1, G[g].lo[0], G[g].hi[0],
-                    G[g].lo[1], G[g].hi[1], G[g].lo[2], G[g].hi[2]);
-        }
-    }
     {  // the scene's bounding sphere: centre of the box around the candidates' spheres, radius to the farthest of them
         const Cand* cd = reinterpret_cast<const Cand*>(sc->blob.data() + h.off_cands);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};

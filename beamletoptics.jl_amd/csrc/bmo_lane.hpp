@@ -90,8 +90,7 @@ struct SceneView {
     CDouble* n_table;
     CDouble* coefs;
     const BMO_KONST struct Cand* cands;  // candidate table (fill_candidates)
-    const BMO_KONST struct CandGroup* groups = nullptr;  // runs of the candidate table with a box around them (fill_cand_groups), n_groups of them
-    int32_t n_objects, n_lambda, n_cands, n_groups = 0;
+    int32_t n_objects, n_lambda, n_cands;
     double eps_srf, eps_ray, eps_ins, mt_keps, mt_leps, grad_h;
     int32_t march_iters;
 };
@@ -814,96 +813,6 @@ inline int fill_candidates(const bmo_object* objects, int n_objects, const bmo_s
     return n;
 }
 
-// Two-level candidate table (round 4).  trace_all looks at every entry of the table for every ray (cull_miss: ~25 vector instructions per
-// entry and level — 11 % of the kernel with the 40 entries of BASELINE config 5, where two thirds of them belong to lens trains the ray
-// never comes near).  A group is a RUN of consecutive entries (slot order is the reference's order and stays as it is) inside an axis-aligned
-// box around their bounding spheres; the collection tests the box first and walks the run only if some lane's ray meets the box.  A ray that
-// misses the box misses every sphere in it — as a half line: a sphere it would only meet behind its origin is `receding` for cull_miss — so
-// a skipped run is exactly a run of entries cull_miss rejects (the box is inflated against rounding: never a miss the spheres would not give).
-struct CandGroup {
-    double lo[3], hi[3];
-    int32_t first, count;
-};
-// ray (half line from `pos`) against the box: slabs with IEEE minNum / maxNum (a 0 * inf of an axis-parallel ray on a face drops out)
-BMO_HD bool ray_meets_box(const double lox, const double loy, const double loz, const double hix, const double hiy, const double hiz, const d3& pos, const d3& dir) {
-    const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z;
-    const double ax = (lox - pos.x) * ix, bx = (hix - pos.x) * ix;
-    const double ay = (loy - pos.y) * iy, by = (hiy - pos.y) * iy;
-    const double az = (loz - pos.z) * iz, bz = (hiz - pos.z) * iz;
-    const double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), 0.0));
-    const double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
-    return !(tmax < tmin);  // (NaN on either side: not a proven miss)
-}
-// Groups of a candidate table (host side, at scene creation).  Cost model of one collection: every group costs a box test (about 1.2
-// entry tests), and its entries are walked with a probability that grows with the surface of its box:
-// cost = sum over groups of 1.2 + min(1, 6 A_group / A_scene) * entries.  Start from one group per entry and merge the ADJACENT pair that raises
-// that sum least, as long as a merge lowers it (runs only: slot order is the reference's order).  Entries without a bounding sphere make
-// their box infinite.  Returns the number of groups written to `out` (room for n of them); fewer than 2: not worth a second level.
-inline int fill_cand_groups(const Cand* cd, int n, CandGroup* out) {
-    struct Box {
-        double lo[3], hi[3];
-    };
-    if (n <= 0) return 0;
-    const double BOX_COST = 1.2, BIG = 1e30;
-    auto box_of = [&](int a, int b) {
-        Box x{{BIG, BIG, BIG}, {-BIG, -BIG, -BIG}};
-        for (int i = a; i < b; ++i) {
-            const double c[3] = {cd[i].cx, cd[i].cy, cd[i].cz};
-            const bool bounded = cd[i].R >= 0.0 && cd[i].R < BIG;
-            for (int q = 0; q < 3; ++q) {
-                const double l = bounded ? c[q] - cd[i].R : -BIG, h = bounded ? c[q] + cd[i].R : BIG;
-                x.lo[q] = l < x.lo[q] ? l : x.lo[q];
-                x.hi[q] = h > x.hi[q] ? h : x.hi[q];
-            }
-        }
-        return x;
-    };
-    auto area = [](const Box& x) {
-        const double d0 = x.hi[0] - x.lo[0], d1 = x.hi[1] - x.lo[1], d2 = x.hi[2] - x.lo[2];
-        return 2.0 * (d0 * d1 + d1 * d2 + d2 * d0);
-    };
-    const double a_scene = area(box_of(0, n));
-    if (!(a_scene > 0.0) || !(a_scene < BIG)) return 0;
-    // probability that a group's entries are walked: the surface ratio x 6, at most 1 — the rays of a solve are not spread evenly over the
-    // scene, they run along the lens train they belong to (three trains side by side: a third of the rays meets each train's box, not the
-    // 6 % its surface is of the scene's)
-    auto walked = [&](const Box& x) {
-        const double p = 6.0 * area(x) / a_scene;
-        return p < 1.0 ? p : 1.0;
-    };
-    // runs as [start[g], start[g + 1])
-    int ng = n;
-    int* start = new int[n + 1];
-    for (int i = 0; i <= n; ++i) start[i] = i;
-    for (;;) {
-        int best = -1;
-        double best_delta = 0.0;  // only merges that lower the cost
-        for (int g = 0; g + 1 < ng; ++g) {
-            const int a = start[g], m = start[g + 1], b = start[g + 2];
-            const double together = BOX_COST + walked(box_of(a, b)) * (b - a);
-            const double apart = 2 * BOX_COST + walked(box_of(a, m)) * (m - a) + walked(box_of(m, b)) * (b - m);
-            if (together - apart < best_delta) best_delta = together - apart, best = g;
-        }
-        if (best < 0) break;
-        for (int g = best + 1; g < ng; ++g) start[g] = start[g + 1];
-        --ng;
-    }
-    for (int g = 0; g < ng; ++g) {
-        const Box x = box_of(start[g], start[g + 1]);
-        CandGroup G;
-        for (int q = 0; q < 3; ++q) {  // inflated against the rounding of the slab test
-            const double m = 1e-9 * ((x.hi[q] - x.lo[q]) + (x.hi[q] < 0 ? -x.hi[q] : x.hi[q]) + (x.lo[q] < 0 ? -x.lo[q] : x.lo[q])) + 1e-12;
-            G.lo[q] = x.lo[q] - m;
-            G.hi[q] = x.hi[q] + m;
-        }
-        G.first = start[g];
-        G.count = start[g + 1] - start[g];
-        out[g] = G;
-    }
-    delete[] start;
-    return ng;
-}
-
 // Per-lane memory of one tracing step besides the child cache (device: columns of LDS, host: a local array), m[c * stride]:
 //   0..2  end point of the march that produced the best hit so far; after the step: the normal of the winning hit
 //   3..5  origin of the ray (re-read where a candidate is set up instead of being held in registers across the marches)
@@ -1192,35 +1101,20 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                     const bool collect = in_pass && !done && o_lo < o_hi;
                     if (c1 > 0 && BMO_WAVE_ANY(collect)) {
                         const d3 p0 = lm.get3(3);
-                        // the table run by run (CandGroup: a run is walked only if some lane's ray meets the box around it), or as one run
-                        const int n_runs = S.n_groups > 1 ? S.n_groups : 1;
                         BMO_NOUNROLL
-                        for (int g = 0; g < n_runs; ++g) {
-                            int r0 = 0, r1 = c1;  // the run, as indices into this chunk of the table
-                            if (S.n_groups > 1) {
-                                const BMO_KONST CandGroup& G = S.groups[g];
-                                r0 = G.first - c0;
-                                r1 = r0 + G.count;
-                                r0 = r0 < 0 ? 0 : r0;
-                                r1 = r1 > c1 ? c1 : r1;
-                                if (r0 >= r1) continue;
-                                if (!BMO_WAVE_ANY(collect && ray_meets_box(G.lo[0], G.lo[1], G.lo[2], G.hi[0], G.hi[1], G.hi[2], p0, dir0))) continue;
+                        for (int i0 = 0; i0 < c1; i0 += 4) {
+                            bool want[4];
+                            const BMO_KONST Cand* cp = S.cands + (c0 + i0);  // (the table is padded: entries behind the last one are zeros)
+                            for (int u = 0; u < 4; ++u) {
+                                const BMO_KONST Cand& cd = cp[u];
+                                const int32_t co = cd.obj, cs = cd.sid;
+                                // (only the retrace probe narrows the object range or excludes an object)
+                                const bool in_range = RETR ? ((co >= o_lo) & (co < o_hi) & (co != skip_obj)) : true;
+                                want[u] = (i0 + u < c1) & collect & in_range & (cs != tested_shape) & !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
                             }
-                            BMO_NOUNROLL
-                            for (int i0 = r0; i0 < r1; i0 += 4) {
-                                bool want[4];
-                                const BMO_KONST Cand* cp = S.cands + (c0 + i0);  // (the table is padded: entries behind the last one are zeros)
-                                for (int u = 0; u < 4; ++u) {
-                                    const BMO_KONST Cand& cd = cp[u];
-                                    const int32_t co = cd.obj, cs = cd.sid;
-                                    // (only the retrace probe narrows the object range or excludes an object)
-                                    const bool in_range = RETR ? ((co >= o_lo) & (co < o_hi) & (co != skip_obj)) : true;
-                                    want[u] = (i0 + u < r1) & collect & in_range & (cs != tested_shape) & !cull_miss(cd.cx, cd.cy, cd.cz, cd.R, p0, dir0);
-                                }
-                                for (int u = 0; u < 4; ++u) {
-                                    mask |= (unsigned long long)want[u] << (i0 + u);
-                                    if (BMO_WAVE_ANY(want[u])) wave_mask |= 1ull << (i0 + u);
-                                }
+                            for (int u = 0; u < 4; ++u) {
+                                mask |= (unsigned long long)want[u] << (i0 + u);
+                                if (BMO_WAVE_ANY(want[u])) wave_mask |= 1ull << (i0 + u);
                             }
                         }
                     }

@@ -81,13 +81,6 @@ void run(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts*
     std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)) + 3);  // (+ 3: read four per trip)
     S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
     S.cands = cands.data();
-    std::vector<CandGroup> groups((size_t)std::max(1, S.n_cands));  // second level of the candidate table, as the engine builds it
-    {
-        const char* e = getenv("BMO_CAND_GROUPS");
-        const int ng = (!(e && atoi(e) == 0) && S.n_cands >= 16) ? fill_cand_groups(cands.data(), S.n_cands, groups.data()) : 0;
-        S.groups = groups.data();
-        S.n_groups = ng > 1 ? ng : 0;
-    }
     S.eps_srf = d->eps_srf;
     S.eps_ray = d->eps_ray;
     S.eps_ins = d->eps_ins;
@@ -398,13 +391,6 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
     std::vector<Cand> cands((size_t)std::max(1, fill_candidates(d->objects, d->n_objects, d->shapes, nullptr)) + 3);  // (+ 3: read four per trip)
     S.n_cands = fill_candidates(d->objects, d->n_objects, d->shapes, cands.data());
     S.cands = cands.data();
-    std::vector<CandGroup> groups((size_t)std::max(1, S.n_cands));  // second level of the candidate table, as the engine builds it
-    {
-        const char* e = getenv("BMO_CAND_GROUPS");
-        const int ng = (!(e && atoi(e) == 0) && S.n_cands >= 16) ? fill_cand_groups(cands.data(), S.n_cands, groups.data()) : 0;
-        S.groups = groups.data();
-        S.n_groups = ng > 1 ? ng : 0;
-    }
     S.eps_srf = d->eps_srf;
     S.eps_ray = d->eps_ray;
     S.eps_ins = d->eps_ins;

@@ -70,48 +70,3 @@ def test_many_objects_engine(oracle):
         compare(eng.trace(b, 200), ref, 0.0, "104 objects, engine")
     finally:
         eng.close()
-
-
-# ------------------------------------------------------------------------------------------------ the candidate table's second level
-# (bmo_lane.hpp CandGroup: runs of the table inside a box, walked only when some lane's ray meets the box): with it, without it
-# (BMO_CAND_GROUPS=0, read when a scene is created) and the oracle agree bit for bit — on the cell above, whose groups straddle the
-# 64-slot chunks of the table, and on BASELINE config 5, three lens trains side by side (the scene the second level is there for).
-def _c5_case(n):
-    import scenes
-
-    system, _ = scenes.c5_scene()
-    b = scenes.c5_bundle(n)
-    return bmo.CompiledScene(system, b.lambdas), b
-
-
-@pytest.mark.parametrize("groups", ["1", "0"])
-def test_candidate_groups_lane_code(oracle, monkeypatch, groups):
-    monkeypatch.setenv("BMO_CAND_GROUPS", groups)
-    system, origin, d = _cell()
-    b = _bundle(64, origin, d)
-    scene = bmo.CompiledScene(system, b.lambdas)
-    compare(emu_trace(scene, b, 200), oracle.trace(scene, b, 200, threads=8), 0.0, "104 objects, lane code, groups " + groups)
-    scene5, b5 = _c5_case(192)
-    compare(emu_trace(scene5, b5, 100), oracle.trace(scene5, b5, 100, threads=8), 0.0, "config 5, lane code, groups " + groups)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("groups", ["1", "0"])
-def test_candidate_groups_engine(oracle, monkeypatch, groups):
-    monkeypatch.setenv("BMO_CAND_GROUPS", groups)
-    system, origin, d = _cell()
-    b = _bundle(2048, origin, d)
-    scene = bmo.CompiledScene(system, b.lambdas)
-    ref = oracle.trace(scene, b, 200, threads=16)
-    eng = bmo.Engine(scene, 0)
-    try:
-        compare(eng.trace(b, 200), ref, 0.0, "104 objects, engine, groups " + groups)
-    finally:
-        eng.close()
-    scene5, b5 = _c5_case(6144)
-    ref5 = oracle.trace(scene5, b5, 100, threads=16)
-    eng = bmo.Engine(scene5, 0)
-    try:
-        compare(eng.trace(b5, 100), ref5, 0.0, "config 5, engine, groups " + groups)
-    finally:
-        eng.close()

@@ -7,6 +7,6 @@ for rep in 1 2 3; do
     BMO_ENGINE_LIB=$PWD/$lib python bench.py --workload $wl --steps $steps --warmup 1 --cpu-sample 0 --no-extras 2>gpurun_out/ab.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('%-34s %-4s value %.3e  ms/step %7.3f  kernel avg %.3f ms x %d launches' % ('$lib', '$wl', d['value'], d['ms_per_step'], r['avg_launch_ms'], r['launches_per_step']))"
+print('%-34s %-4s value %.3e  ms/step %7.3f  kernel/solve %.3f ms, %d launches' % ('$lib', '$wl', d['value'], d['ms_per_step'], r['kernel_ms_per_solve'], r['launches_per_step']))"
   done
 done
