@@ -38,6 +38,10 @@
 #define BMO_NOUNROLL
 #endif
 
+#if !defined(BMO_DUAL_PASSES)
+#define BMO_DUAL_PASSES 1  /* evaluations per dual-number gradient: 1 (duals of three partials), 2 (two + one), 3 (one each) — see normal_of */
+#endif
+
 namespace bmo {
 
 #if defined(BMO_EMU_STATS)  // host-only instrumentation of the test emulator (tools/emu_stats.py)
@@ -151,53 +155,131 @@ BMO_HD double jabs(double x) { return fabs(x); }
 BMO_HD double jsqrt(double x) { return sqrt(x); }
 BMO_HD double val(double x) { return x; }
 
-// ------------------------------------------------------------------ ForwardDiff.Dual, 3 partials
-struct Dual {
-    double v, a, b, c;
+// ------------------------------------------------------------------ ForwardDiff.Dual with N partials
+// (N = 3 is the reference's gradient of three; the kernels evaluate the partials in passes of fewer — normal_of — because the register need
+//  of a leaf grows with N: 27 vector registers for the value alone, 86 with three partials.  Every rule below treats the partials one by one,
+//  so a pass over a subset computes exactly the numbers the full gradient holds for that subset.)
+template <int N>
+struct DualN {
+    double v;
+    double p[N];
 };
-BMO_HD double val(const Dual& x) { return x.v; }
-BMO_HD Dual operator+(const Dual& x, const Dual& y) { return {x.v + y.v, x.a + y.a, x.b + y.b, x.c + y.c}; }
-BMO_HD Dual operator-(const Dual& x, const Dual& y) { return {x.v - y.v, x.a - y.a, x.b - y.b, x.c - y.c}; }
-BMO_HD Dual operator+(const Dual& x, double r) { return {x.v + r, x.a, x.b, x.c}; }
-BMO_HD Dual operator+(double r, const Dual& x) { return {r + x.v, x.a, x.b, x.c}; }
-BMO_HD Dual operator-(const Dual& x, double r) { return {x.v - r, x.a, x.b, x.c}; }
-BMO_HD Dual operator-(double r, const Dual& x) { return {r - x.v, -x.a, -x.b, -x.c}; }
-BMO_HD Dual operator-(const Dual& x) { return {-x.v, -x.a, -x.b, -x.c}; }
-BMO_HD Dual operator*(const Dual& x, const Dual& y) {
-    return {x.v * y.v, (x.a * y.v) + (y.a * x.v), (x.b * y.v) + (y.b * x.v), (x.c * y.v) + (y.c * x.v)};
+using Dual = DualN<3>;
+#define BMO_DN template <int N> BMO_HD
+BMO_DN double val(const DualN<N>& x) { return x.v; }
+BMO_DN DualN<N> operator+(const DualN<N>& x, const DualN<N>& y) {
+    DualN<N> r;
+    r.v = x.v + y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] + y.p[q];
+    return r;
 }
-BMO_HD Dual operator*(const Dual& x, double r) { return {x.v * r, x.a * r, x.b * r, x.c * r}; }
-BMO_HD Dual operator*(double r, const Dual& x) { return {r * x.v, x.a * r, x.b * r, x.c * r}; }
-BMO_HD Dual operator/(const Dual& x, double r) { return {x.v / r, x.a / r, x.b / r, x.c / r}; }
-BMO_HD Dual jsqrt(const Dual& x) {
-    double s = sqrt(x.v);
-    double d = 1.0 / (2.0 * s);
-    // sqrt(0) with all-zero partials keeps them zero (ForwardDiff's NaN-safe partial scaling; pinned by the reference's narrow
-    // point-source KAT, test/runtests.jl:2755-2761 — see oracle/jl_math.hpp)
-    const bool keep = !(fabs(d) < kinf()) && x.a == 0 && x.b == 0 && x.c == 0;  // selects, not a branch
-    return {s, keep ? x.a : x.a * d, keep ? x.b : x.b * d, keep ? x.c : x.c * d};
+BMO_DN DualN<N> operator-(const DualN<N>& x, const DualN<N>& y) {
+    DualN<N> r;
+    r.v = x.v - y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] - y.p[q];
+    return r;
 }
-BMO_HD Dual jabs(const Dual& x) {
+BMO_DN DualN<N> operator+(const DualN<N>& x, double c) {
+    DualN<N> r = x;
+    r.v = x.v + c;
+    return r;
+}
+BMO_DN DualN<N> operator+(double c, const DualN<N>& x) {
+    DualN<N> r = x;
+    r.v = c + x.v;
+    return r;
+}
+BMO_DN DualN<N> operator-(const DualN<N>& x, double c) {
+    DualN<N> r = x;
+    r.v = x.v - c;
+    return r;
+}
+BMO_DN DualN<N> operator-(double c, const DualN<N>& x) {
+    DualN<N> r;
+    r.v = c - x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = -x.p[q];
+    return r;
+}
+BMO_DN DualN<N> operator-(const DualN<N>& x) {
+    DualN<N> r;
+    r.v = -x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = -x.p[q];
+    return r;
+}
+BMO_DN DualN<N> operator*(const DualN<N>& x, const DualN<N>& y) {
+    DualN<N> r;
+    r.v = x.v * y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * y.v) + (y.p[q] * x.v);
+    return r;
+}
+BMO_DN DualN<N> operator*(const DualN<N>& x, double c) {
+    DualN<N> r;
+    r.v = x.v * c;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * c;
+    return r;
+}
+BMO_DN DualN<N> operator*(double c, const DualN<N>& x) {
+    DualN<N> r;
+    r.v = c * x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * c;
+    return r;
+}
+BMO_DN DualN<N> operator/(const DualN<N>& x, double c) {
+    DualN<N> r;
+    r.v = x.v / c;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] / c;
+    return r;
+}
+BMO_DN DualN<N> jsqrt(const DualN<N>& x) {
+    const double s = sqrt(x.v);
+    const double d = 1.0 / (2.0 * s);
+    // sqrt(0) with zero partials keeps them zero (ForwardDiff's NaN-safe partial scaling; pinned by the reference's narrow point-source KAT,
+    // test/runtests.jl:2755-2761 — see oracle/jl_math.hpp).  The rule reads "ALL partials zero"; it is applied partial by partial here, which
+    // is the same thing wherever it can matter: every sqrt of the leaves takes a sum of squares, and a sum of squares that is exactly 0 has
+    // every term 0 and with it every partial (2 u du = 0 du) — a zero value with a non-zero partial next to a zero one does not occur, and
+    // if an earlier non-finite partial made it occur, that partial stays non-finite and the normal falls back to the numeric gradient either way.
+    const bool at_zero = !(fabs(d) < kinf());
+    DualN<N> r;
+    r.v = s;
+    for (int q = 0; q < N; ++q) r.p[q] = (at_zero && x.p[q] == 0) ? x.p[q] : x.p[q] * d;  // selects, not a branch
+    return r;
+}
+BMO_DN DualN<N> jabs(const DualN<N>& x) {
     const bool neg = sgn(x.v);
-    return {neg ? -x.v : x.v, neg ? -x.a : x.a, neg ? -x.b : x.b, neg ? -x.c : x.c};
+    DualN<N> r;
+    r.v = neg ? -x.v : x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = neg ? -x.p[q] : x.p[q];
+    return r;
 }
-BMO_HD Dual jmax(const Dual& x, const Dual& y) {
-    bool yw = (y.v > x.v) | (sgn(y.v) < sgn(x.v));
-    double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
-    return {jmax(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
+BMO_DN DualN<N> jmax(const DualN<N>& x, const DualN<N>& y) {
+    const bool yw = (y.v > x.v) | (sgn(y.v) < sgn(x.v));
+    const double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    DualN<N> r;
+    r.v = jmax(x.v, y.v);
+    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * dx) + (y.p[q] * dy);
+    return r;
 }
-BMO_HD Dual jmin(const Dual& x, const Dual& y) {
-    bool yw = (y.v < x.v) | (sgn(y.v) > sgn(x.v));
-    double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
-    return {jmin(x.v, y.v), (x.a * dx) + (y.a * dy), (x.b * dx) + (y.b * dy), (x.c * dx) + (y.c * dy)};
+BMO_DN DualN<N> jmin(const DualN<N>& x, const DualN<N>& y) {
+    const bool yw = (y.v < x.v) | (sgn(y.v) > sgn(x.v));
+    const double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    DualN<N> r;
+    r.v = jmin(x.v, y.v);
+    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * dx) + (y.p[q] * dy);
+    return r;
 }
-BMO_HD Dual jmax(const Dual& x, double y) {
-    double dx = ((y > x.v) | (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
-    return {jmax(x.v, y), x.a * dx, x.b * dx, x.c * dx};
+BMO_DN DualN<N> jmax(const DualN<N>& x, double y) {
+    const double dx = ((y > x.v) | (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
+    DualN<N> r;
+    r.v = jmax(x.v, y);
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * dx;
+    return r;
 }
-BMO_HD Dual jmin(const Dual& x, double y) {
-    double dx = ((y < x.v) | (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
-    return {jmin(x.v, y), x.a * dx, x.b * dx, x.c * dx};
+BMO_DN DualN<N> jmin(const DualN<N>& x, double y) {
+    const double dx = ((y < x.v) | (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
+    DualN<N> r;
+    r.v = jmin(x.v, y);
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * dx;
+    return r;
 }
 
 template <class T>
@@ -257,27 +339,39 @@ BMO_HD T slab2(const T& dx, const T& dy) {
 // ------------------------------------------------------------------ aspheres / acylinders
 // AsphericalLensSDF.jl:133-307, AcylindricalSDF.jl.  T = double (aspheres: never differentiated, :5) or Dual (acylinders
 // use the default normal_fd).  Extra ForwardDiff rules: Dual/Dual, Real/Dual, literal powers, run-time integer powers, clamp.
-BMO_HD Dual operator/(const Dual& x, const Dual& y) {
-    double ia = 1.0 / y.v, fb = -(x.v / (y.v * y.v));
-    return {x.v / y.v, (x.a * ia) + (y.a * fb), (x.b * ia) + (y.b * fb), (x.c * ia) + (y.c * fb)};
+BMO_DN DualN<N> operator/(const DualN<N>& x, const DualN<N>& y) {
+    const double ia = 1.0 / y.v, fb = -(x.v / (y.v * y.v));
+    DualN<N> r;
+    r.v = x.v / y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * ia) + (y.p[q] * fb);
+    return r;
 }
-BMO_HD Dual operator/(double x, const Dual& y) {
-    double divv = x / y.v, f = -(divv / y.v);
-    return {divv, y.a * f, y.b * f, y.c * f};
+BMO_DN DualN<N> operator/(double x, const DualN<N>& y) {
+    const double divv = x / y.v, f = -(divv / y.v);
+    DualN<N> r;
+    r.v = divv;
+    for (int q = 0; q < N; ++q) r.p[q] = y.p[q] * f;
+    return r;
 }
 BMO_HD bool lt(double a, double b) { return a < b; }
-BMO_HD bool lt(const Dual& a, double b) { return a.v < b; }
-BMO_HD bool lt(double a, const Dual& b) { return a < b.v; }
-BMO_HD bool lt(const Dual& a, const Dual& b) { return a.v < b.v; }
+BMO_DN bool lt(const DualN<N>& a, double b) { return a.v < b; }
+BMO_DN bool lt(double a, const DualN<N>& b) { return a < b.v; }
+BMO_DN bool lt(const DualN<N>& a, const DualN<N>& b) { return a.v < b.v; }
 BMO_HD double lit2(double x) { return x * x; }
 BMO_HD double lit3(double x) { return x * x * x; }
-BMO_HD Dual lit2(const Dual& x) {
-    double d = 2 * x.v;
-    return {x.v * x.v, x.a * d, x.b * d, x.c * d};
+BMO_DN DualN<N> lit2(const DualN<N>& x) {
+    const double d = 2 * x.v;
+    DualN<N> r;
+    r.v = x.v * x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * d;
+    return r;
 }
-BMO_HD Dual lit3(const Dual& x) {
-    double d = 3 * (x.v * x.v);
-    return {x.v * x.v * x.v, x.a * d, x.b * d, x.c * d};
+BMO_DN DualN<N> lit3(const DualN<N>& x) {
+    const double d = 3 * (x.v * x.v);
+    DualN<N> r;
+    r.v = x.v * x.v * x.v;
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * d;
+    return r;
 }
 BMO_HD double ipow(double x, int n) {  // Base.power_by_squaring (small exponents multiply out like literal_pow)
     if (n == 0) return 1.0;
@@ -292,18 +386,32 @@ BMO_HD double ipow(double x, int n) {  // Base.power_by_squaring (small exponent
     }
     return r;
 }
-BMO_HD Dual ipow(const Dual& x, int n) {  // Dual(v^n, (partials * n) * v^(n-1)); zero partials short-cut
-    double ev = ipow(x.v, n);
-    if (n == 0 || (x.a == 0 && x.b == 0 && x.c == 0)) return {ev, 0, 0, 0};
-    double f = ipow(x.v, n - 1);
-    return {ev, (x.a * n) * f, (x.b * n) * f, (x.c * n) * f};
+BMO_DN DualN<N> ipow(const DualN<N>& x, int n) {  // Dual(v^n, (partials * n) * v^(n-1)); zero partials short-cut (partial by partial: 0 * n * f = 0 for the finite f of n >= 1)
+    const double ev = ipow(x.v, n);
+    const double f = n == 0 ? 0.0 : ipow(x.v, n - 1);
+    DualN<N> r;
+    r.v = ev;
+    for (int q = 0; q < N; ++q) r.p[q] = (n == 0 || x.p[q] == 0) ? 0.0 : (x.p[q] * n) * f;
+    return r;
 }
 BMO_HD double knan() { return kinf() - kinf(); }
 BMO_HD double mknan(double) { return knan(); }
-BMO_HD Dual mknan(const Dual&) { return {knan(), knan(), knan(), knan()}; }
+BMO_DN DualN<N> mknan(const DualN<N>&) {
+    DualN<N> r;
+    r.v = knan();
+    for (int q = 0; q < N; ++q) r.p[q] = knan();
+    return r;
+}
 BMO_HD double jsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 BMO_HD double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }
-BMO_HD Dual clamp01(const Dual& x) { return x.v > 1.0 ? Dual{1.0, 0, 0, 0} : (x.v < 0.0 ? Dual{0.0, 0, 0, 0} : x); }
+BMO_DN DualN<N> clamp01(const DualN<N>& x) {
+    DualN<N> r = x;
+    if (x.v > 1.0 || x.v < 0.0) {
+        r.v = x.v > 1.0 ? 1.0 : 0.0;
+        for (int q = 0; q < N; ++q) r.p[q] = 0.0;
+    }
+    return r;
+}
 // aspheric_equation :133-141 and the first component of gradient_aspheric_equation :147-156, one pass over the coefficients
 template <class T>
 BMO_HD void asph_eval(const T& r, double c, double k, CDouble* a, int na, T& z, T& g) {
@@ -399,7 +507,7 @@ BMO_HD T asph_distance(bool convex, const T& r, const T& z, double c, double k, 
 BMO_HD double asph_leaf(CShape& s, CDouble* coefs, double r, double y) {
     return asph_distance<double>(s.kind == BMO_SHAPE_ASPH_CONVEX, r, y, 1 / s.p[0], s.p[1], s.p[2], coefs + s.child_begin, s.child_count, s.p[3]);
 }
-BMO_HD Dual asph_leaf(CShape&, CDouble*, const Dual&, const Dual&) { return Dual{knan(), knan(), knan(), knan()}; }
+BMO_DN DualN<N> asph_leaf(CShape&, CDouble*, const DualN<N>& r, const DualN<N>&) { return mknan(r); }
 
 // leaf SDFs; `pt` is in the parent's frame (world, or the meniscus frame)
 // EXT ("extended shapes" level of the kernel): 0 = the spherical / primitive leaves only; 1 = + MeniscusLensSDF; 2 = + the aspheric
@@ -663,18 +771,52 @@ BMO_HD double sdf_any(const SceneView& S, const ShapeHead& H, CShape& s, const d
 // normal_fd (AbstractSDF.jl:90-95): dual-number gradient, NaN => numeric_gradient (:81-88).
 template <int EXT>
 BMO_HD d3 normal_of(const SceneView& S, CShape& sh, const d3& p) {
+#if !defined(BMO_STUB_NORMAL)  // (developer builds: the numeric gradient alone — WRONG results, register / timing experiments only)
     {
 #if defined(BMO_EMU_STATS)
         ++g_emu_normal;
 #endif
-        v3<Dual> x{{p.x, 1, 0, 0}, {p.y, 0, 1, 0}, {p.z, 0, 0, 1}};
-        Dual y = sdf_simple<Dual, EXT>(S, sh, x);
-        d3 n = normalize_inv(d3{y.a, y.b, y.c});
+        // ForwardDiff.gradient evaluates the sdf ONCE on duals of three partials.  BMO_DUAL_PASSES > 1 takes the three partials from two or
+        // three evaluations on duals of fewer (DualN above: the same numbers, partial by partial; the emulator == oracle corpus is green in
+        // every mode) — a leaf on duals of three needs 86 vector registers and holds every step kernel at 168 (3 waves per SIMD).  Measured in
+        // round 4 (profiles/r04_ab_scheduling.txt item 8) and NOT the default: two + one at 128 registers keeps the march and the normal
+        // code spill-free (176 B of scratch, all of it once per level around the interaction) and 4 waves per SIMD, and is 3.5 % SLOWER on
+        // config 2 and even on config 5 — the extra evaluation costs what the fourth wave gives; one each in a loop spills 212 - 348 B.
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#if BMO_DUAL_PASSES == 1
+        {
+            v3<DualN<3>> x{{p.x, {1, 0, 0}}, {p.y, {0, 1, 0}}, {p.z, {0, 0, 1}}};
+            const DualN<3> y = sdf_simple<DualN<3>, EXT>(S, sh, x);
+            g0 = y.p[0], g1 = y.p[1], g2 = y.p[2];
+        }
+#elif BMO_DUAL_PASSES == 2
+        {
+            v3<DualN<2>> x{{p.x, {1, 0}}, {p.y, {0, 1}}, {p.z, {0, 0}}};
+            const DualN<2> y = sdf_simple<DualN<2>, EXT>(S, sh, x);
+            g0 = y.p[0], g1 = y.p[1];
+        }
+        {
+            v3<DualN<1>> x{{p.x, {0}}, {p.y, {0}}, {p.z, {1}}};
+            const DualN<1> y = sdf_simple<DualN<1>, EXT>(S, sh, x);
+            g2 = y.p[0];
+        }
+#else
+        BMO_NOUNROLL
+        for (int ax = 0; ax < 3; ++ax) {  // one code site, three trips: d/dx, d/dy, d/dz
+            v3<DualN<1>> x{{p.x, {ax == 0 ? 1.0 : 0.0}}, {p.y, {ax == 1 ? 1.0 : 0.0}}, {p.z, {ax == 2 ? 1.0 : 0.0}}};
+            const DualN<1> y = sdf_simple<DualN<1>, EXT>(S, sh, x);
+            g0 = ax == 0 ? y.p[0] : g0;
+            g1 = ax == 1 ? y.p[0] : g1;
+            g2 = ax == 2 ? y.p[0] : g2;
+        }
+#endif
+        d3 n = normalize_inv(d3{g0, g1, g2});
         if (!isnan_(n.x) && !isnan_(n.y) && !isnan_(n.z)) return n;
 #if defined(BMO_EMU_STATS)
         ++g_emu_normal_fd;
 #endif
     }
+#endif
     const double e = S.grad_h;
     double g0 = 0, g1 = 0, g2 = 0;
     BMO_NOUNROLL
