@@ -833,6 +833,11 @@ struct GaussRecDev {
     int64_t ncap;  // straight into their record, planes 11 r + c
     double* G;     // staging of the reflected child's rays: [21][gcap], planes 7 r + c
     int64_t gcap;
+    // wavelength index and wavelength of the beamlet: constant along a lane (children included), carried in the lane memory from the level
+    // that loaded them — the node tables are indexed by beam, and with the roots in coherence order neighbouring lanes hold beams far apart:
+    // six scattered reads per lane and level were 1.5 GB of the Gaussian kernel's HBM reads per config-3 solve
+    int32_t li;
+    double lambda;
     __device__ void put_next(int r, const RayS& x) const {
         const int64_t b = 11 * (int64_t)r;
         N[(b + 0) * ncap + j] = x.pos.x;
@@ -891,11 +896,10 @@ struct GaussRecDev {
         a.oplC = D[35 * cap + j];
         a.oplW = D[36 * cap + j];
         a.oplD = D[37 * cap + j];
-        a.li = nodes.li[node];
-        a.lambda = nodes.lambda[node];
-        a.l0 = nodes.aux[(int64_t)node * 4 + 0];
-        a.w0 = nodes.aux[(int64_t)node * 4 + 1];
-        a.E0 = {nodes.aux[(int64_t)node * 4 + 2], nodes.aux[(int64_t)node * 4 + 3]};
+        a.li = li;
+        a.lambda = lambda;
+        a.l0 = a.w0 = 0.0;  // (the splitter branch takes l0, w0, E0 from load(); nothing else reads them)
+        a.E0 = {0.0, 0.0};
         return a;
     }
     __device__ GaussIn load() const {
@@ -909,8 +913,8 @@ struct GaussRecDev {
         g.oplC = D[35 * cap + j];
         g.oplW = D[36 * cap + j];
         g.oplD = D[37 * cap + j];
-        g.li = nodes.li[node];
-        g.lambda = nodes.lambda[node];
+        g.li = li;
+        g.lambda = lambda;
         g.l0 = nodes.aux[(int64_t)node * 4 + 0];
         g.w0 = nodes.aux[(int64_t)node * 4 + 1];
         g.E0 = {nodes.aux[(int64_t)node * 4 + 2], nodes.aux[(int64_t)node * 4 + 3]};
@@ -1035,7 +1039,13 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
                 rt = retrace_lane(P, node, k);
                 no_hint = rt.old >= 0 && !rt.probe;
             }
-            GaussRecDev rec{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap};
+            // (lane memory slots 9, 10: wavelength index and wavelength; loaded where the lane's first record of this launch is read)
+            const LaneMem lmw{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
+            if (b == 0) {
+                lmw.m[9 * lmw.stride] = (double)P.nodes.li[node];
+                lmw.m[10 * lmw.stride] = P.nodes.lambda[node];
+            }
+            GaussRecDev rec{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap, (int32_t)lmw.m[9 * lmw.stride], lmw.m[10 * lmw.stride]};
             if ((flags & F_DEAD) || (RETR && rt.old >= 0 && !rt.probe && !rt.fresh_allowed)) {
                 status = BMO_NODE_RMAX;
                 rec.clear_hits();
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
                 ChildCache cc{reinterpret_cast<double*>(scratch + 64) + threadIdx.x, BMO_BLOCK, 0};
                 const LaneMem lm{reinterpret_cast<double*>(scratch + 64) + BMO_CC_MAX * BMO_BLOCK + threadIdx.x, BMO_BLOCK};
                 if (RETR && no_hint) {
-                    GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap}};
+                    GaussRecDevNoHint rn{{D, I, P.nodes, cap, j, node, N.d, N.cap, P.gstage, P.gstage_cap, rec.li, rec.lambda}};
                     gauss_step_rec<EXT, RETR>(S, rn, o, calls, cc, lm, rt.probe, rt.probe_obj, rt.fresh_allowed, &rt.missed);
                 } else if (RETR) {
                     const GaussTailDev tail{P.old, rt.old, k, rt.old_n};
