@@ -10,4 +10,4 @@ g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,
 trap 'make -s -B -C tests/emu' EXIT
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 python -m pytest tests/test_fuzz.py tests/test_leaf_kinds.py tests/test_cull.py tests/test_retrace.py \
-    tests/test_degenerate_rays.py -x -q -m "not gpu" -p no:cacheprovider "$@"
+    tests/test_retrace_stale.py tests/test_many_objects.py tests/test_degenerate_rays.py -x -q -m "not gpu" -p no:cacheprovider "$@"
