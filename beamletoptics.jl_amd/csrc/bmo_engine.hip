@@ -305,7 +305,13 @@ __device__ inline int prefix_rank(unsigned long long mask) {
 // of a block publish their ballot counts in LDS, thread 0 issues ONE atomic per counter, and every wave derives its
 // own offsets.  Block layout in the next chunk: [survivors of wave 0..3][child pairs of wave 0..3].
 #ifndef BMO_BLOCK
-#define BMO_BLOCK 256  /* lanes per workgroup of the step kernels (a multiple of 64, at most 256) */
+// Lanes per workgroup of the step kernels (a multiple of 64, at most 256).  Round 4: ONE wave per workgroup.  A workgroup keeps its LDS and
+// its place among a CU's resident workgroups until its LAST wave is done, and the waves of a ragged launch end far apart (one grazing march
+// holds a wave for milliseconds): with four waves per workgroup the ragged config-2 bundle ran with a third to two thirds of the wave slots
+// EMPTY in the middle of its launch although thousands of workgroups were waiting (profiles/r04_timeline_c2v.txt) — 9.3 ms per solve, 7.5 ms
+// with one wave per workgroup; the coherent bundles pay 0.5 % for four times as many workgroups (c2 3.42 -> 3.44 ms, c5 8.12 -> 8.17 ms;
+// profiles/r04_ab_scheduling.txt item 9).  The slot allocation below is per workgroup either way; with one wave its barriers compile away.
+#define BMO_BLOCK 64
 #endif
 struct SlotAlloc {
     unsigned long long surv_base, child_base, node_base;

@@ -2,7 +2,7 @@
 # A/B of engine builds on one GPU box, interleaved: tools/ab.sh <workload> <steps> lib1 lib2 ...   (libs relative to the repo root)
 wl=$1; steps=$2; shift 2
 mkdir -p gpurun_out
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for lib in "$@"; do
     BMO_ENGINE_LIB=$PWD/$lib python bench.py --workload $wl --steps $steps --warmup 1 --cpu-sample 0 --no-extras 2>gpurun_out/ab.err | python -c "
 import json,sys
