@@ -1872,6 +1872,10 @@ struct bmo_trace_result {
     std::mutex rt_mu;
     bool rt_built = false;
     DevBuf rt_rec_start, rt_rec_obj, rt_first_child, rt_rec_loc, rt_chunks;
+    // time of every tile of this solve's first launch (StepParams::tile_cost), copied from the batch: a retrace of this solution with a
+    // freshly uploaded batch (bmo_retrace: the wrappers upload the root heads on every call) orders its tiles by it
+    DevBuf tile_cost;
+    int64_t tile_n = 0;
     std::vector<int64_t> det_count, det_offset;
     // host views (filled by bmo_result_view / bmo_result_view_select), all page-locked; each part is materialised on first request
     bool nodes_viewed = false, hits_viewed = false;
@@ -2334,6 +2338,10 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
                     hipLaunchKernelGGL(iota_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, (int32_t*)batch->lpt_ids.p, (int64_t)n_blocks);
                     batch->tile_n = (int64_t)n_blocks;
                 }
+                if (!batch->cost_valid && prev && prev->tile_n == (int64_t)n_blocks && prev->tile_cost.p) {  // feedback from the solution that is retraced
+                    HIP_TRY(hipMemcpyAsync(batch->tile_cost.p, prev->tile_cost.p, (size_t)n_blocks * 4, hipMemcpyDeviceToDevice, stream));
+                    batch->cost_valid = true;
+                }
                 if (batch->cost_valid) {
                     size_t tb = batch->lpt_tmp.bytes;
                     HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(batch->lpt_tmp.p, tb, (const uint32_t*)batch->tile_cost.p, (uint32_t*)batch->lpt_keys.p,
@@ -2462,6 +2470,9 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     R->n_nodes = n_nodes;
     R->n_steps = steps;
     R->kernel_ms = kernel_ms;
+    if (batch->cost_valid && batch->tile_n > 0 && batch->tile_cost.p && !R->tile_cost.alloc((size_t)batch->tile_n * 4)) {  // (best effort)
+        if (hipMemcpyAsync(R->tile_cost.p, batch->tile_cost.p, (size_t)batch->tile_n * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess) R->tile_n = batch->tile_n;
+    }
     // Everything below is queued behind ONE synchronisation at the end: temporaries stay alive until then (`keep`: a block that went
     // back to the pool could be handed to a view running on another stream), counts are read back last.
     std::vector<std::unique_ptr<DevBuf>> keep;
