@@ -1175,6 +1175,11 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                                 }
                                 const double d = sdf_any<EXT>(S, H, s, pos, bc, cc, moved);
                                 if (phase == OUTSIDE) {
+                                    // (the receding test below only when the distance GREW with this step: outside the bounding ball and moving away
+                                    //  from it an exact sdf grows with every step, and a march that is converging skips 16 instructions per trip;
+                                    //  for the inexact leaves the test merely comes a step later — it proves misses, it never makes one.  Round 4:
+                                    //  ragged bundle - 1.3 %, the others - 0.2 %)
+                                    const bool growing = d > dist;
                                     dist = d;
                                     t0 += d;
                                     it += 1;
@@ -1184,10 +1189,13 @@ BMO_HD Hit tracing_step(const SceneView& S, const d3& pos_in, const d3& dir0, in
                                     } else {
                                         // outside the bounding sphere and receding (the backward march runs along -dir: dot(co, -dir) =
                                         // -dot(co, dir) exactly): provable miss, skip the rest of the 1000 evaluations
+                                        bool recede = false;
+                                        if (growing) {
                                         const double R = s.bs_radius;
                                         const d3 co{pos.x - s.bs_center[0], pos.y - s.bs_center[1], pos.z - s.bs_center[2]};
                                         const double cd = dot3(co, dir0);
-                                        const bool recede = R >= 0.0 && dot3(co, co) > R * R && ((st & ST_BACK) ? cd < 0.0 : cd > 0.0);
+                                        recede = R >= 0.0 && dot3(co, co) > R * R && ((st & ST_BACK) ? cd < 0.0 : cd > 0.0);
+                                        }
                                         if (recede || (exact && !(st & ST_BACK) && t0 > lim)  // provable loser of the nearest-hit selection
                                             || !(it <= S.march_iters))
                                             st = 0;
