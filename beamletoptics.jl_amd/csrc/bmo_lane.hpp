@@ -287,6 +287,27 @@ struct v3 {
     T x, y, z;
 };
 
+// Keeps a leaf's arithmetic INSIDE the branch of its kind: the kind of a shape is wave-uniform, the dispatch over it a chain of scalar
+// branches, and whatever the optimiser may evaluate speculatively in front of such a branch (a norm with its square root, hoisted out of
+// the branch that needs it) is evaluated for every leaf of every kind.  An empty asm on the local point pins everything that depends on it
+// behind the branch it stands in (device only; no instruction is emitted).
+BMO_HD void pin(double& x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BMO_NO_PIN)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+template <int N>
+BMO_HD void pin(DualN<N>& x) {
+    pin(x.v);  // (the value alone: pinning the partials too costs 1 % and 20 B of scratch — measured)
+}
+template <class T>
+BMO_HD void pin3(v3<T>& p) {
+    pin(p.x);
+    pin(p.y);
+    pin(p.z);
+}
 BMO_HD double dot3(const d3& a, const d3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 BMO_HD double norm3(const d3& a) { return sqrt(dot3(a, a)); }
 BMO_HD d3 sub3(const d3& a, const d3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -519,12 +540,9 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
     // points of use they, not the arithmetic, set the pace of the march); `kind` comes from the caller, who has read it already
     const double P0 = s.p[0], P1 = s.p[1], P2 = s.p[2], P3 = s.p[3];
     v3<T> p = to_local(s, pt);
-    if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
-        T r = norm3t(p.x, p.y, p.z);
-        return kind == BMO_SHAPE_SPHERE ? r - P0 : r;
-    }
     if (kind == BMO_SHAPE_PLANO || kind == BMO_SHAPE_CYLINDER || kind == BMO_SHAPE_RING) {
         // SphericalLensSDF.jl:60-65, PrimitiveSDF.jl:71-76, :151-166
+        pin3(p);
         double ra, ha, off, sub;
         if (kind == BMO_SHAPE_PLANO) {
             ra = P1 / 2;
@@ -548,6 +566,7 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         return slab2(jabs(r) - ra, jabs(h) - ha);
     }
     if (kind == BMO_SHAPE_CONVEX || kind == BMO_SHAPE_CUTSPHERE) {  // SphericalLensSDF.jl:219-232, PrimitiveSDF.jl:112-124
+        pin3(p);
         double radius = P0, w, height;
         T q1 = norm2(p.x, p.z), q2;
         if (kind == BMO_SHAPE_CONVEX) {
@@ -566,6 +585,7 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         return norm2(q1 - w, q2 - height);
     }
     if (kind == BMO_SHAPE_CONCAVE) {  // SphericalLensSDF.jl:159-170
+        pin3(p);
         double radius = P0, dia = P1, sag = P2;
         T x0 = p.x + 0.0, z0 = p.z + 0.0;
         T y1 = p.y + sag / 2;
@@ -575,7 +595,12 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         T sdf2 = norm3t(x0, y2, z0) - radius;
         return jmax(sdf1, -sdf2);
     }
+#if defined(BMO_DEV_NO_BOX)
+    if (false) {
+#else
     if (kind == BMO_SHAPE_BOX || kind == BMO_SHAPE_PRISM) {  // PrimitiveSDF.jl:41-46, :204-210
+#endif
+        pin3(p);
         T qx = jabs(p.x) - P0, qy = jabs(p.y) - P1, qz = jabs(p.z) - P2;
         T box = norm3t(jmax(qx, 0.0), jmax(qy, 0.0), jmax(qz, 0.0)) + jmin(jmax(qx, jmax(qy, qz)), 0.0);
         if (kind == BMO_SHAPE_BOX) return box;
@@ -619,6 +644,15 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
             return jmax(l, -c);
         }
     }
+#if !defined(BMO_DEV_NO_SPHERE)  // (developer builds: leaf kinds compiled out one by one)
+    // LAST in the chain on purpose (round 4): at its head the optimiser evaluated this branch's norm — a square root — speculatively in front of the
+    // kind dispatch, for EVERY leaf of every kind: config 2 on SURVEY 8(d)'s bundle 3.27 ms of kernel with it there, 3.06 without it
+    if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
+        pin3(p);
+        T r = norm3t(p.x, p.y, p.z);
+        return kind == BMO_SHAPE_SPHERE ? r - P0 : r;
+    }
+#endif
     return T{} + kinf();
 }
 
