@@ -982,12 +982,13 @@ __global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES_GAUSS) void step_kernel_ga
     uint32_t calls = 0;
     const int64_t ncap = P.nxt.cap;
     int32_t pend_node = -1;  // node of the reflected child this lane keeps for itself in P.gkeep (StepParams::pend), -1: none
-    // (measured, profiles/r04_ab_scheduling.txt: in this kernel the kept child costs more registers than the saved launch gives back —
-    //  228 B of scratch per lane instead of 196, config 3 10.56 ms per solve against 10.34 — so it is compiled in with -DBMO_GAUSS_KEEP only)
-#if defined(BMO_GAUSS_KEEP)
-    const bool keep = P.gkeep != nullptr;
-#else
+    // (measured twice, profiles/r04_ab_scheduling.txt items 5 and 11: while the leaves' dispatch still cost this kernel 196 B of scratch the kept
+    //  child made it 228 B and config 3 2 % slower, 10.56 against 10.34 ms; with the pinned dispatch — 140 B, 164 with the kept child — it is
+    //  2 % FASTER, 9.41 against 9.62 ms, and one launch per solve.  -DBMO_NO_GAUSS_KEEP compiles it out.)
+#if defined(BMO_NO_GAUSS_KEEP)
     const bool keep = false;
+#else
+    const bool keep = P.gkeep != nullptr;
 #endif
     // accumulators and header of a record whose rays are in place already
     auto write_tail = [&](const Chunk& T, int64_t slot, int32_t nd, int32_t kk, int32_t ho, int32_t hs, int32_t fl, double lenA, double lenB, double oplC,

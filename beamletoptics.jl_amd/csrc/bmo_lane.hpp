@@ -304,7 +304,7 @@ BMO_HD void pin(DualN<N>& x) {
 }
 template <class T>
 BMO_HD void pin3(v3<T>& p) {
-    pin(p.x);
+    pin(p.x);  // (pinning x alone — every square root of the leaves depends on it — measures the same)
     pin(p.y);
     pin(p.z);
 }
@@ -540,7 +540,11 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
     // points of use they, not the arithmetic, set the pace of the march); `kind` comes from the caller, who has read it already
     const double P0 = s.p[0], P1 = s.p[1], P2 = s.p[2], P3 = s.p[3];
     v3<T> p = to_local(s, pt);
-    if (kind == BMO_SHAPE_PLANO || kind == BMO_SHAPE_CYLINDER || kind == BMO_SHAPE_RING) {
+    // leaf class of the kinds 0 .. 15, four bits each (1 plano / cylinder / ring, 2 convex / cut sphere, 3 concave, 4 box / prism, 5 sphere /
+    // point): two scalar instructions in front of a dense dispatch instead of a tree of compares over the sparse kind values
+    // (round 4: config 2 - 4.3 %, config 5 - 4.7 %)
+    const unsigned cls = (unsigned)((0x0005041214032150ull >> (4 * (kind & 15))) & 15ull) * (kind < 16 ? 1u : 0u);
+    if (cls == 1) {  // PLANO | CYLINDER | RING
         // SphericalLensSDF.jl:60-65, PrimitiveSDF.jl:71-76, :151-166
         pin3(p);
         double ra, ha, off, sub;
@@ -565,7 +569,7 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         T h = kind == BMO_SHAPE_PLANO ? p.y - off : p.y;
         return slab2(jabs(r) - ra, jabs(h) - ha);
     }
-    if (kind == BMO_SHAPE_CONVEX || kind == BMO_SHAPE_CUTSPHERE) {  // SphericalLensSDF.jl:219-232, PrimitiveSDF.jl:112-124
+    if (cls == 2) {  // CONVEX | CUTSPHERE  // SphericalLensSDF.jl:219-232, PrimitiveSDF.jl:112-124
         pin3(p);
         double radius = P0, w, height;
         T q1 = norm2(p.x, p.z), q2;
@@ -584,7 +588,7 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         if (a < w) return height - q2;
         return norm2(q1 - w, q2 - height);
     }
-    if (kind == BMO_SHAPE_CONCAVE) {  // SphericalLensSDF.jl:159-170
+    if (cls == 3) {  // CONCAVE  // SphericalLensSDF.jl:159-170
         pin3(p);
         double radius = P0, dia = P1, sag = P2;
         T x0 = p.x + 0.0, z0 = p.z + 0.0;
@@ -595,11 +599,7 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
         T sdf2 = norm3t(x0, y2, z0) - radius;
         return jmax(sdf1, -sdf2);
     }
-#if defined(BMO_DEV_NO_BOX)
-    if (false) {
-#else
-    if (kind == BMO_SHAPE_BOX || kind == BMO_SHAPE_PRISM) {  // PrimitiveSDF.jl:41-46, :204-210
-#endif
+    if (cls == 4) {  // BOX | PRISM  // PrimitiveSDF.jl:41-46, :204-210
         pin3(p);
         T qx = jabs(p.x) - P0, qy = jabs(p.y) - P1, qz = jabs(p.z) - P2;
         T box = norm3t(jmax(qx, 0.0), jmax(qy, 0.0), jmax(qz, 0.0)) + jmin(jmax(qx, jmax(qy, qz)), 0.0);
@@ -644,15 +644,13 @@ BMO_HD T sdf_leaf(CShape& s, const int kind, const v3<T>& pt, CDouble* coefs) {
             return jmax(l, -c);
         }
     }
-#if !defined(BMO_DEV_NO_SPHERE)  // (developer builds: leaf kinds compiled out one by one)
     // LAST in the chain on purpose (round 4): at its head the optimiser evaluated this branch's norm — a square root — speculatively in front of the
     // kind dispatch, for EVERY leaf of every kind: config 2 on SURVEY 8(d)'s bundle 3.27 ms of kernel with it there, 3.06 without it
-    if (kind == BMO_SHAPE_SPHERE || kind == BMO_SHAPE_POINT) {  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
+    if (cls == 5) {  // SPHERE | POINT  // SphericalLensSDF.jl:86-89, runtests.jl:943-946
         pin3(p);
         T r = norm3t(p.x, p.y, p.z);
         return kind == BMO_SHAPE_SPHERE ? r - P0 : r;
     }
-#endif
     return T{} + kinf();
 }
 
