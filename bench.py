@@ -33,6 +33,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SURVEY.md §8d algorithmic bytes per bounce (segment 64 + hint 8 read; intersection 40 + segment 64 + hint 8 written) by beam kind
 BYTES_PER_BOUNCE = {0: 184, 1: 280, 2: 584}
+# the bound the path actually runs into: one vector instruction of a 64-wide wave occupies a SIMD's 16 FP64 lanes for 4 cycles,
+# 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock (MI355X_MICROARCH.md) = 6.1e11 wave-instructions/s = the 78.6 TFLOP/s vector-FP64 peak in FMAs
+VALU_PEAK_WAVE_INST_PER_S = 256 * 4 * 2.4e9 / 4
 KERNEL_NAME = {0: "step_kernel<RAY>", 1: "step_kernel<POLARIZED>", 2: "step_kernel_gauss"}
 
 
@@ -171,6 +174,21 @@ def measured_traffic(name, n, r_max):
     if not tj:
         return None, None
     return 2 * tj["fetch_size_bytes"] + tj["write_size_bytes"], tj["source"]
+
+
+def valu_issue(name, n, r_max, kernel_ms_per_solve):
+    """The VALU side of the accounting: vector instructions the step kernels issue per solve (a property of the workload and the build: the
+    SQ_INSTS_VALU pass committed under profiles/) over the kernel time measured live in THIS run, against the SIMDs' issue peak."""
+    tp = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(tp) or n != DEFAULT_RAYS.get(name) or r_max != 100 or kernel_ms_per_solve <= 0:
+        return None
+    tj = json.load(open(tp)).get(name) or {}
+    if not tj.get("valu_wave_instructions"):
+        return None
+    rate = tj["valu_wave_instructions"] / (kernel_ms_per_solve * 1e-3)
+    return {"wave_instructions_per_solve": tj["valu_wave_instructions"], "achieved": rate, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instructions/s",
+            "frac": rate / VALU_PEAK_WAVE_INST_PER_S, "fp64_arithmetic_share": tj["valu_fp64_arithmetic"] / tj["valu_wave_instructions"],
+            "source": tj["valu_source"], "note": "peak at the 2.4 GHz maximum clock; every vector instruction (FP64 arithmetic, selects, compares, moves) takes one issue slot"}
 
 
 def roofline_of(case, c, kernel_ms, launches, steps, traffic=None, traffic_src=None):
@@ -460,6 +478,7 @@ def main():
             },
             "roofline": roofline_of(case, mine, kernel_ms, launches, args.steps, traffic, traffic_src),
         }
+        out["roofline"]["valu_issue"] = valu_issue(name, n_local, args.r_max, kernel_ms / max(args.steps, 1))
         if local_only is not None:
             out["one_gpu_same_workload"] = {"value": local_only, "unit": "intersections/s",
                                             "what": "rank 0, same shard, solves only (no exchange step), measured before the timed region"}

@@ -60,5 +60,17 @@ def test_bench_line_objects_on_the_gpu():
     assert isinstance(rl, dict) and isinstance(cb, dict)
     assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
     assert rl["kernel_ms_per_solve"] > 0 and rl["kernel_ms_per_solve"] >= rl["avg_launch_ms"]
+    assert rl["valu_issue"] is None  # the committed counter pass is of the default size only: no VALU figure for another bundle size
     assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and "all_cores" in cb and "lane_code_all_cores" in cb
     assert abs(out["vs_baseline"] - out["value"] / cb["value"]) <= 1e-9 * out["vs_baseline"]
+
+
+def test_valu_issue_figure_reads_the_committed_counter_pass():
+    """roofline.valu_issue: vector instructions per solve from the committed SQ pass over the live kernel time, against 256 CUs x 4 SIMDs x 2.4 GHz / 4."""
+    bench = _bench()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))["c2s"]
+    v = bench.valu_issue("c2s", 1 << 20, 100, 3.0)
+    assert v["peak"] == 256 * 4 * 2.4e9 / 4 and v["wave_instructions_per_solve"] == tj["valu_wave_instructions"]
+    assert abs(v["achieved"] - tj["valu_wave_instructions"] / 3.0e-3) <= 1e-6 * v["achieved"] and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-12
+    assert 0.2 < v["fp64_arithmetic_share"] < 0.8
+    assert bench.valu_issue("c2s", 1 << 16, 100, 3.0) is None and bench.valu_issue("c2s", 1 << 20, 50, 3.0) is None

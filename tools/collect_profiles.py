@@ -35,6 +35,16 @@ for wdir in sorted(glob.glob(src + "/*/")):
         # the 128-byte requests of a coalesced read at 64 B)
         traffic[w] = {"fetch_size_bytes": tot["FETCH_SIZE"] * 1024, "write_size_bytes": tot["WRITE_SIZE"] * 1024, "launches": tot["launches"],
                       "source": f"profiles/{tag}_pmc_{w}.txt: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over the step kernels of ONE solve, python3 bench.py --workload {w} --steps 1 --warmup 0"}
+    # the VALU side of the accounting (bench.py's roofline.valu_issue): vector instructions per solve and the FP64 arithmetic among them
+    p3 = os.path.join(wdir, "sq3_summary.txt")
+    if w in traffic and os.path.exists(p3):
+        m = re.search(r"total ms [\d.]+ (\{.*\})", open(p3).read())
+        if m:
+            c = {k: float(v) for k, v in ast.literal_eval(m.group(1)).items()}
+            if c.get("SQ_INSTS_VALU"):
+                traffic[w]["valu_wave_instructions"] = c["SQ_INSTS_VALU"]
+                traffic[w]["valu_fp64_arithmetic"] = sum(c.get("SQ_INSTS_VALU_" + k + "_F64", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
+                traffic[w]["valu_source"] = f"profiles/{tag}_pmc_{w}.txt, pass sq3 (SQ_INSTS_VALU, SQ_INSTS_VALU_{{ADD,MUL,FMA,TRANS}}_F64 over the step kernels of ONE solve)"
     with open(os.path.join(dst, f"{tag}_pmc_{w}.txt"), "w") as f:
         f.write(f"# rocprofv3 --pmc passes of ONE solve of workload {w} (tools/profile_round.sh; per launch of the step kernels, then totals).\n# SQ cycle counters are in quad-cycles; FETCH_SIZE / WRITE_SIZE in KB.\n")
         for name in ("sq", "sq2", "sq3", "fetch", "write"):
