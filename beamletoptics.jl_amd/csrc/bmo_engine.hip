@@ -374,10 +374,25 @@ __device__ __forceinline__ unsigned tile_of_block(int mode, unsigned b, unsigned
     if (mode == 2) return (b & 1u) ? grid - 1u - (b >> 1) : (b >> 1);
     return b;
 }
-#ifndef BMO_MIN_WAVES
-#define BMO_MIN_WAVES 3  /* <= 168 VGPRs.  Round 3: with the scene tables read by scalar loads tracing_step is spill-free at 168 registers and 3 waves/SIMD
-                            beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5 (profiles/r03_ab_scalar_scene.txt); 4 (128) still spills in the march */
+// Waves per SIMD a step-kernel variant is compiled for = its register budget (3: 168 VGPRs, 4: 128).  Round 3: with the scene tables read by scalar
+// loads tracing_step is spill-free at 168 registers, and 3 waves/SIMD beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5
+// (profiles/r03_ab_scalar_scene.txt).  Round 4, after the leaf-dispatch work: at 128 registers the Ray kernel of the plain-shapes level spills
+// 100 - 132 B per lane, all of it at bounce-level depth and none inside a march, and the fourth wave is worth more than that — on LARGE launches
+// (profiles/r04_ab_scheduling.txt item 14: config 2 - 4 %, config 5 - 9 %, the ragged bundle - 9 %).  A launch of a few thousand waves is as long as its slowest
+// marches, and those run slower with three neighbours on their SIMD than with two (2^18 rays of config 2: + 2 %), so the Ray kernels of that level are
+// compiled twice and the launch picks by its size (`wide_min_waves` below).  The other variants are compiled once, for the count that measured faster
+// (tools/ext_times.py; the extended-shape levels and the polarized kernels spill 216 - 540 B at 128 registers, partly inside the normals' code).
+// -DBMO_MIN_WAVES=n compiles every variant for n (A/B builds).
+template <int KIND, int EXT, bool RETR>
+constexpr int step_waves() {
+#if defined(BMO_MIN_WAVES)
+    return BMO_MIN_WAVES;
+#else
+    if (KIND == BMO_BEAM_POLARIZED && EXT == 0) return 4;  // three singlets, 2^18 PolarizedRays: fresh 0.317 against 0.341 ms, retrace 0.297 against 0.327
+    if (RETR && EXT == 2) return 4;                        // asphere objective: retrace 2.60 against 3.06 ms (Ray), 2.75 against 3.21 (PolarizedRay)
+    return 3;
 #endif
+}
 #ifndef BMO_MIN_WAVES_GAUSS
 #define BMO_MIN_WAVES_GAUSS 3
 #endif
@@ -390,8 +405,8 @@ __device__ __forceinline__ unsigned tile_of_block(int mode, unsigned b, unsigned
 // INW: beam splitters are handled inside the fused loop (the launches of a beam tree's tail: fewer launches, no launch waits for the
 // slowest march of every generation); without it a split ends the wave's loop and both children wait for the next launch, which costs
 // less register room — the large launches of the BASELINE configs run 2 - 7 % faster that way (profiles/r03_ab_inwave.txt).
-template <int KIND, int EXT, bool RETR, bool INW>
-__global__ __launch_bounds__(BMO_BLOCK, BMO_MIN_WAVES) void step_kernel(StepParams P) {
+template <int KIND, int EXT, bool RETR, bool INW, int WAVES = step_waves<KIND, EXT, RETR>()>
+__global__ __launch_bounds__(BMO_BLOCK, WAVES) void step_kernel(StepParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const SceneView S = view_of((const char*)P.blob, &P.hdr);  // scene tables: global memory, scalar loads (bmo_lane.hpp)
     char* scratch = lds;
@@ -2168,10 +2183,16 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
     // + block_alloc scratch + per-lane columns: child cache (BMO_CC_MAX doubles) and the lane memory of tracing_step (BMO_LANE_MEM doubles)
     const size_t lds_bytes = (use_lds ? blob_bytes : 0) + 64 + (size_t)(BMO_CC_MAX + BMO_LANE_MEM) * BMO_BLOCK * 8;
     void (*kern)(StepParams) = nullptr, (*kern_inw)(StepParams) = nullptr;  // kern_inw: the Beam kernels' variant with in-loop beam splitters
+    void (*kern_wide)(StepParams) = nullptr, (*kern_inw_wide)(StepParams) = nullptr;  // the 4-waves-per-SIMD builds of the two, for large launches (step_waves)
     const int ext = scene->hdr.has_asphere ? 2 : (scene->hdr.has_meniscus ? 1 : 0);  // extended-shapes level of the kernels (bmo_lane.hpp sdf_leaf)
 #if defined(BMO_DEV_RAY_LDS_ONLY)  // developer build (kernel work on one variant): everything else is refused, nothing falls back
     if constexpr (KIND == BMO_BEAM_RAY) {
-        if (!prev && ext == 0) kern = &step_kernel<BMO_BEAM_RAY, 0, false, false>, kern_inw = &step_kernel<BMO_BEAM_RAY, 0, false, true>;
+        if (!prev && ext == 0) {
+            kern = &step_kernel<BMO_BEAM_RAY, 0, false, false>, kern_inw = &step_kernel<BMO_BEAM_RAY, 0, false, true>;
+#if !defined(BMO_MIN_WAVES)
+            kern_wide = &step_kernel<BMO_BEAM_RAY, 0, false, false, 4>, kern_inw_wide = &step_kernel<BMO_BEAM_RAY, 0, false, true, 4>;
+#endif
+        }
     }
     if (!kern) return fail(BMO_ERR_UNSUPPORTED, "developer build: only step_kernel<RAY> is compiled in");
 #elif defined(BMO_DEV_GAUSS_ONLY)  // developer build: the fresh GaussianBeamlet kernel of the plain-shapes level only
@@ -2188,11 +2209,18 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         else kern = ext == 2 ? &step_kernel<KIND, 2, false, false> : (ext == 1 ? &step_kernel<KIND, 1, false, false> : &step_kernel<KIND, 0, false, false>);
         if (prev) kern_inw = ext == 2 ? &step_kernel<KIND, 2, true, true> : (ext == 1 ? &step_kernel<KIND, 1, true, true> : &step_kernel<KIND, 0, true, true>);
         else kern_inw = ext == 2 ? &step_kernel<KIND, 2, false, true> : (ext == 1 ? &step_kernel<KIND, 1, false, true> : &step_kernel<KIND, 0, false, true>);
+#if !defined(BMO_MIN_WAVES)
+        if constexpr (KIND == BMO_BEAM_RAY) {
+            if (!prev && ext == 0) kern_wide = &step_kernel<BMO_BEAM_RAY, 0, false, false, 4>, kern_inw_wide = &step_kernel<BMO_BEAM_RAY, 0, false, true, 4>;
+        }
+#endif
     }
 #endif
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         if (kern_inw) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_inw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (kern_wide) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (kern_inw_wide) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_inw_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
 
     int64_t n_nodes = n;
@@ -2378,7 +2406,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
         // (step_kernel_gauss handles P.inwave_cap itself: the GaussianBeamlet branch above assigns no kern_inw)
-        void (*const launch_kern)(StepParams) = (inwave_cap > 0 && kern_inw) ? kern_inw : kern;
+        // (the 4-waves-per-SIMD build from two full rounds of the device on — 2 x 256 CUs x 16 waves —, the 3-waves one below: step_waves)
+        const char* const wide_env = getenv("BMO_WIDE_MIN_WAVES");  // (read per launch: the tests switch it between solves)
+        const int64_t wide_min_waves = wide_env ? atoll(wide_env) : 8192;
+        const bool wide = kern_wide && n_waves > wide_min_waves;
+        void (*const launch_kern)(StepParams) = (inwave_cap > 0 && kern_inw) ? (wide ? kern_inw_wide : kern_inw) : (wide ? kern_wide : kern);
         if (!launch_kern) return fail(BMO_ERR_INTERNAL, "no step kernel selected for this beam kind / scene level");
         hipLaunchKernelGGL(launch_kern, dim3(n_blocks), dim3(BMO_BLOCK), lds_bytes, stream, P);
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps + 1], stream));

@@ -4,6 +4,8 @@ plain bundle order — read when a batch is uploaded), the reflected child a lan
 out — from the end of the chunk in the first solve of a batch, slowest first by the previous solve's per-tile times from the second on.
 Every combination gives the oracle's beams, rays, hits and detector rows, bit for bit; beam nodes keep the bundle's numbering whatever
 the slot order is (`System.jl:463-468`: result order = bundle order x BFS order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -50,6 +52,30 @@ def test_root_orders_and_tile_feedback_do_not_change_results(oracle, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ragged", "disc"])
+def test_wide_kernels_give_the_same_results(oracle, monkeypatch, case):
+    """The Ray kernels of the plain-shapes level exist twice — compiled for 3 and for 4 waves per SIMD (168 / 128 registers, `step_waves`) — and a
+    launch picks by its size (`BMO_WIDE_MIN_WAVES`, default 8192 waves).  Same lane code, other register allocation and spills: same bits."""
+    scene, b = (_ragged_case if case == "ragged" else _disc_case)(8192)
+    ref = oracle.trace(scene, b, 100, threads=16)
+    eng = bmo.Engine(scene, 0)
+    try:
+        dev = eng.upload(b)
+        try:
+            for wide_min in ("0", "1000000000", "0"):
+                monkeypatch.setenv("BMO_WIDE_MIN_WAVES", wide_min)
+                res = eng.trace_device(dev, 100)
+                try:
+                    compare(eng.result_view(res), ref, 0.0, f"{case}, BMO_WIDE_MIN_WAVES={wide_min}")
+                finally:
+                    eng.free_result(res)
+        finally:
+            eng.free_batch(dev)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_kept_reflected_children_through_a_splitter_chain(oracle):
     """Four thin splitters in a row (the transmitted beam meets the next one): a lane keeps ONE reflected child (StepParams::pend), a split while one waits goes to the next
     launch's chunk, kept children are taken up when their lane's beam ends — beam tree, order and detector rows as the oracle has them."""
@@ -74,8 +100,13 @@ def test_kept_reflected_children_through_a_splitter_chain(oracle):
     eng = bmo.Engine(scene, 0)
     try:
         dev = eng.upload(b)
-        for solve in range(2):
-            res = eng.trace_device(dev, 100)
+        for solve in range(3):
+            if solve == 2:  # ... and through the 4-waves-per-SIMD build of the kernel
+                os.environ["BMO_WIDE_MIN_WAVES"] = "0"
+            try:
+                res = eng.trace_device(dev, 100)
+            finally:
+                os.environ.pop("BMO_WIDE_MIN_WAVES", None)
             compare(eng.result_view(res), ref, 0.0, f"splitter chain, solve {solve}")
             eng.free_result(res)
         eng.free_batch(dev)
