@@ -380,7 +380,7 @@ __device__ __forceinline__ unsigned tile_of_block(int mode, unsigned b, unsigned
 // 100 - 132 B per lane, all of it at bounce-level depth and none inside a march, and the fourth wave is worth more than that — on LARGE launches
 // (profiles/r04_ab_scheduling.txt item 14: config 2 - 4 %, config 5 - 9 %, the ragged bundle - 9 %).  A launch of a few thousand waves is as long as its slowest
 // marches, and those run slower with three neighbours on their SIMD than with two (2^18 rays of config 2: + 2 %), so the Ray kernels of that level are
-// compiled twice and the launch picks by its size (`wide_min_waves` below).  The other variants are compiled once, for the count that measured faster
+// compiled twice and the launch picks by its size (`wide_min_waves` below: 4 096 waves, the device filled once at 4 per SIMD).  The other variants are compiled once, for the count that measured faster
 // (tools/ext_times.py; the extended-shape levels and the polarized kernels spill 216 - 540 B at 128 registers, partly inside the normals' code).
 // -DBMO_MIN_WAVES=n compiles every variant for n (A/B builds).
 template <int KIND, int EXT, bool RETR>
@@ -2406,10 +2406,11 @@ int run_trace(bmo_scene* scene, bmo_device_batch* batch, const bmo_trace_opts* o
         }
         HIP_TRY(hipEventRecord(ctxp->step_ev[2 * steps], stream));
         // (step_kernel_gauss handles P.inwave_cap itself: the GaussianBeamlet branch above assigns no kern_inw)
-        // (the 4-waves-per-SIMD build from two full rounds of the device on — 2 x 256 CUs x 16 waves —, the 3-waves one below: step_waves)
+        // (the 4-waves-per-SIMD build for a launch that fills the device at that occupancy — 256 CUs x 16 waves —, the 3-waves one below: step_waves.
+        //  Between 4 096 and ~10 000 waves the two scenes measured disagree — config 5 - 13 % / - 6 %, config 2 + 2 % / + 3 % — and the larger effect decides.)
         const char* const wide_env = getenv("BMO_WIDE_MIN_WAVES");  // (read per launch: the tests switch it between solves)
-        const int64_t wide_min_waves = wide_env ? atoll(wide_env) : 8192;
-        const bool wide = kern_wide && n_waves > wide_min_waves;
+        const int64_t wide_min_waves = wide_env ? atoll(wide_env) : 4096;
+        const bool wide = kern_wide && n_waves >= wide_min_waves;
         void (*const launch_kern)(StepParams) = (inwave_cap > 0 && kern_inw) ? (wide ? kern_inw_wide : kern_inw) : (wide ? kern_wide : kern);
         if (!launch_kern) return fail(BMO_ERR_INTERNAL, "no step kernel selected for this beam kind / scene level");
         hipLaunchKernelGGL(launch_kern, dim3(n_blocks), dim3(BMO_BLOCK), lds_bytes, stream, P);

@@ -55,7 +55,7 @@ def test_root_orders_and_tile_feedback_do_not_change_results(oracle, monkeypatch
 @pytest.mark.parametrize("case", ["ragged", "disc"])
 def test_wide_kernels_give_the_same_results(oracle, monkeypatch, case):
     """The Ray kernels of the plain-shapes level exist twice — compiled for 3 and for 4 waves per SIMD (168 / 128 registers, `step_waves`) — and a
-    launch picks by its size (`BMO_WIDE_MIN_WAVES`, default 8192 waves).  Same lane code, other register allocation and spills: same bits."""
+    launch picks by its size (`BMO_WIDE_MIN_WAVES`, default 4096 waves).  Same lane code, other register allocation and spills: same bits."""
     scene, b = (_ragged_case if case == "ragged" else _disc_case)(8192)
     ref = oracle.trace(scene, b, 100, threads=16)
     eng = bmo.Engine(scene, 0)
