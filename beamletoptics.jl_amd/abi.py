@@ -148,8 +148,8 @@ def _check_source_hash(lib):
     if os.environ.get("BMO_ENGINE_LIB"):
         return
     root = os.path.dirname(_HERE)
-    srcs = [os.path.join(_HERE, "csrc", "bmo_engine.hip"), os.path.join(_HERE, "csrc", "bmo_lane.hpp"), os.path.join(_HERE, "csrc", "bmo_readout.inc.hpp"),
-            os.path.join(root, "include", "bmo.h")]
+    srcs = [os.path.join(_HERE, "csrc", "bmo_engine.hip"), os.path.join(_HERE, "csrc", "bmo_lane.hpp"), os.path.join(_HERE, "csrc", "bmo_jlmath.hpp"),
+            os.path.join(_HERE, "csrc", "bmo_readout.inc.hpp"), os.path.join(root, "include", "bmo.h")]
     if not all(os.path.exists(p) for p in srcs):
         return
     import hashlib

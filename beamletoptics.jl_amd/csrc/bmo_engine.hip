@@ -2734,6 +2734,20 @@ __global__ void selftest_minmax_kernel(const double* __restrict__ v, int n, int3
     if (form && atomicCAS(bad, -1, i) == -1) bad[1] = form;
 }
 
+// Julia Base's elementary functions (bmo_jlmath.hpp) on the device, six results per argument: sin, cos, tan, acos(clamped), atan, atan(1, x)
+__host__ __device__ inline void jl_six(double x, double* o) {
+    o[0] = jl::sin(x);
+    o[1] = jl::cos(x);
+    o[2] = jl::tan(x);
+    o[3] = jl::acos(x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x));
+    o[4] = jl::atan(x);
+    o[5] = jl::atan2(1.0, x);
+}
+__global__ void selftest_jl_kernel(const double* __restrict__ x, int n, double* __restrict__ out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) jl_six(x[i], out + (size_t)6 * i);
+}
+
 template <class T>
 int dl(std::vector<T>& h, const void* d, size_t count) {
     h.resize(count);
@@ -2790,6 +2804,43 @@ int bmo_selftest(int32_t device) {
     if (bad[0] != -1)
         return fail(BMO_ERR_INTERNAL, "device min/max differs from the rule: form " + std::to_string(bad[1]) + " on (" + std::to_string(v[(size_t)(bad[0] / n)]) + ", " +
                                           std::to_string(v[(size_t)(bad[0] % n)]) + ")");
+    // ... and the elementary functions (bmo_jlmath.hpp): the device's results against this library's host build of the same header, bit for bit
+    {
+        std::vector<double> xs;
+        unsigned long long s = 0x243F6A8885A308D3ull;
+        auto rnd = [&]() {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            return (double)(s >> 11) * 0x1p-53;
+        };
+        for (int q = 0; q < 4096; ++q) xs.push_back(-7.0 + 14.0 * rnd());            // the reductions by 0 .. 4 pi/2
+        for (int q = 0; q < 2048; ++q) xs.push_back(-1.0 + 2.0 * rnd());             // acos's three ranges, the kernels without reduction
+        for (int q = 0; q < 1024; ++q) xs.push_back((rnd() < 0.5 ? -1.0 : 1.0) * std::ldexp(1.0 + rnd(), (int)(rnd() * 80) - 40));  // atan's five ranges, tiny and large
+        for (int q = 1; q <= 8; ++q)                                                 // next to multiples of pi/2: the three-constant reduction
+            for (int e = -3; e <= 3; ++e) xs.push_back(std::nextafter(q * 1.5707963267948966, e < 0 ? -100.0 : 100.0) + e * 1e-9);
+        for (double sp : {0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.6744, 0.67434, 0.4375, 0.6875, 1.1875, 2.4375, 1e-9, 1e-300, 1e6, 1.5e6, (double)INFINITY, (double)NAN})
+            xs.push_back(sp);
+        const int m = (int)xs.size();
+        DevBuf d_x, d_o;
+        if ((rc = d_x.alloc((size_t)m * 8)) || (rc = d_o.alloc((size_t)m * 48))) return rc;
+        HIP_TRY(hipMemcpy(d_x.p, xs.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(selftest_jl_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, (const double*)d_x.p, m, (double*)d_o.p);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> got((size_t)m * 6);
+        HIP_TRY(hipMemcpy(got.data(), d_o.p, (size_t)m * 48, hipMemcpyDeviceToHost));
+        static const char* const names[6] = {"sin", "cos", "tan", "acos", "atan", "atan(1, x)"};
+        for (int i = 0; i < m; ++i) {
+            double want[6];
+            jl_six(xs[(size_t)i], want);
+            for (int f = 0; f < 6; ++f) {
+                const double a = got[(size_t)6 * i + f], b = want[f];
+                if (!((a != a && b != b) || std::memcmp(&a, &b, 8) == 0)) {
+                    char buf[160];
+                    std::snprintf(buf, sizeof buf, "device %s(%.17g) = %.17g, host build of the same code %.17g", names[f], xs[(size_t)i], a, b);
+                    return fail(BMO_ERR_INTERNAL, buf);
+                }
+            }
+        }
+    }
     return BMO_OK;
 }
 

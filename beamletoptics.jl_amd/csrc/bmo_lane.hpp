@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "../../include/bmo.h"
+#include "bmo_jlmath.hpp"
 
 #if defined(__HIPCC__)
 #define BMO_HD __host__ __device__ __forceinline__
@@ -1427,7 +1428,7 @@ BMO_HD bool e0_orthogonal(const d3& dir, const cx* E0) {  // PolarizedRays.jl:54
     return sqrt(cabs2(d)) <= 1e-14;
 }
 BMO_HD void fresnel(double theta, double n, cx& rs, cx& rp, cx& ts, cx& tp) {  // OpticUtils.jl:121-131
-    double ct = cos(theta), st = sin(theta);
+    double ct = jl::cos(theta), st = jl::sin(theta);  // Base's own sin / cos (bmo_jlmath.hpp): runtests.jl:157 needs their bits
     double x = n * n - st * st;
     cx r = x >= 0.0 ? cx{sqrt(x), 0.0} : cx{0.0, sqrt(-x)};
     cx c{ct, 0};
@@ -1440,7 +1441,7 @@ BMO_HD void fresnel(double theta, double n, cx& rs, cx& rp, cx& ts, cx& tp) {  /
 BMO_HD double angle3d(const d3& a, const d3& b) {  // LinearAlgebraUtils.jl:103-108
     double arg = dot3(a, b) / (norm3(a) * norm3(b));
     arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
-    return acos(arg);
+    return jl::acos(arg);
 }
 
 BMO_HD d3 hit_point(const RayS& r, double t) { return axpy3(r.pos, t, r.dir); }
@@ -1774,14 +1775,14 @@ BMO_HD double gauss_w0_at(const GaussIn& g, double t_total, double temp) {
         d3 y0{g.d.pos.x + il * g.d.dir.x - p0.x, g.d.pos.y + il * g.d.dir.y - p0.y, g.d.pos.z + il * g.d.dir.z - p0.z};
         y_d = norm3(y0);
         y0 = {y0.x / y_d, y0.y / y_d, y0.z / y_d};
-        m_d = tan(3.141592653589793 / 2 - angle3d(y0, g.d.dir));
+        m_d = jl::tan(3.141592653589793 / 2 - angle3d(y0, g.d.dir));
     }
     {
         double il = line_plane_distance3d(p0, g.c.dir, g.w.pos, g.w.dir);
         d3 y0{g.w.pos.x + il * g.w.dir.x - p0.x, g.w.pos.y + il * g.w.dir.y - p0.y, g.w.pos.z + il * g.w.dir.z - p0.z};
         y_w = norm3(y0);
         y0 = {y0.x / y_w, y0.y / y_w, y0.z / y_w};
-        m_w = tan(3.141592653589793 / 2 - angle3d(y0, g.w.dir));
+        m_w = jl::tan(3.141592653589793 / 2 - angle3d(y0, g.w.dir));
     }
     const double n = g.c.n;
     double H = fabs(n * (y_w * m_d - y_d * m_w));
@@ -1804,14 +1805,14 @@ BMO_HD void gauss_parameters_at(const RayS& c, const RayS& wr, const RayS& dr, c
         d3 y0{dr.pos.x + il * dr.dir.x - p0.x, dr.pos.y + il * dr.dir.y - p0.y, dr.pos.z + il * dr.dir.z - p0.z};
         y_d = norm3(y0);
         y0 = {y0.x / y_d, y0.y / y_d, y0.z / y_d};
-        m_d = tan(3.141592653589793 / 2 - angle3d(y0, dr.dir));
+        m_d = jl::tan(3.141592653589793 / 2 - angle3d(y0, dr.dir));
     }
     {
         double il = line_plane_distance3d(p0, c.dir, wr.pos, wr.dir);
         d3 y0{wr.pos.x + il * wr.dir.x - p0.x, wr.pos.y + il * wr.dir.y - p0.y, wr.pos.z + il * wr.dir.z - p0.z};
         y_w = norm3(y0);
         y0 = {y0.x / y_w, y0.y / y_w, y0.z / y_w};
-        m_w = tan(3.141592653589793 / 2 - angle3d(y0, wr.dir));
+        m_w = jl::tan(3.141592653589793 / 2 - angle3d(y0, wr.dir));
     }
     const double n = c.n;
     double H = fabs(n * (y_w * m_d - y_d * m_w));
@@ -1821,7 +1822,7 @@ BMO_HD void gauss_parameters_at(const RayS& c, const RayS& wr, const RayS& dr, c
     w = sqrt(y_d * y_d + y_w * y_w);
     R = E_kt / (w * w);
     const double zz = E_kt / (F_kt * F_kt);
-    psi = -atan2(1.0, sqrt(1 / (R * zz) - 1));
+    psi = -jl::atan2(1.0, sqrt(1 / (R * zz) - 1));
     w0 = H / (n * F_kt);
     if (isnan_(R)) R = 0;
     if (isnan_(psi)) psi = 0;

@@ -27,6 +27,25 @@
 
 #include "../include/bmo.h"
 #include "jl_math.hpp"
+#include "jl_trig.hpp"
+
+// The elementary functions of the step path: Julia Base's own (jl_trig.hpp) — or, for the rule table only (-DBMO_RULE_LIBM=1), the C library's,
+// which is what rounds 1 - 3 used and what fails runtests.jl:157.
+namespace trig {
+#if defined(BMO_RULE_LIBM) && BMO_RULE_LIBM
+inline double sin(double x) { return std::sin(x); }
+inline double cos(double x) { return std::cos(x); }
+inline double tan(double x) { return std::tan(x); }
+inline double acos(double x) { return std::acos(x); }
+inline double atan2(double y, double x) { return std::atan2(y, x); }
+#else
+using jlm::acos;
+using jlm::atan2;
+using jlm::cos;
+using jlm::sin;
+using jlm::tan;
+#endif
+}  // namespace trig
 
 using namespace jl;
 
@@ -695,8 +714,8 @@ bool e0_orthogonal(const D3& dir, const Cx* E0) {
 
 // fresnel_coefficients OpticUtils.jl:121-131
 void fresnel(double theta, double n, Cx& rs, Cx& rp, Cx& ts, Cx& tp) {
-    double cost = std::cos(theta);
-    double st = std::sin(theta);
+    double cost = trig::cos(theta);
+    double st = trig::sin(theta);
     Cx n2s2 = csqrt_real(n * n - st * st);
     Cx c{cost, 0};
     rs = (c - n2s2) / (c + n2s2);
@@ -710,7 +729,7 @@ void fresnel(double theta, double n, Cx& rs, Cx& rp, Cx& ts, Cx& tp) {
 double angle3d(const D3& a, const D3& b) {
     double arg = dot(a, b) / (norm(a) * norm(b));
     arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
-    return std::acos(arg);
+    return trig::acos(arg);
 }
 
 // ---- single-ray interactions ----------------------------------------------
@@ -1140,12 +1159,12 @@ void gauss_parameters(const Node& g, double z, double out[4]) {
     D3 y0{div.pos.x + il * div.dir.x - p0.x, div.pos.y + il * div.dir.y - p0.y, div.pos.z + il * div.dir.z - p0.z};
     double y_d = norm(y0);
     y0 = D3{y0.x / y_d, y0.y / y_d, y0.z / y_d};
-    double m_d = std::tan(M_PI / 2 - angle3d(y0, div.dir));
+    double m_d = trig::tan(M_PI / 2 - angle3d(y0, div.dir));
     il = line_plane_distance3d(p0, chief.dir, waist.pos, waist.dir);
     y0 = D3{waist.pos.x + il * waist.dir.x - p0.x, waist.pos.y + il * waist.dir.y - p0.y, waist.pos.z + il * waist.dir.z - p0.z};
     double y_w = norm(y0);
     y0 = D3{y0.x / y_w, y0.y / y_w, y0.z / y_w};
-    double m_w = std::tan(M_PI / 2 - angle3d(y0, waist.dir));
+    double m_w = trig::tan(M_PI / 2 - angle3d(y0, waist.dir));
     double n = chief.n;
     double H = std::fabs(n * (y_w * m_d - y_d * m_w));
     double lam = g.lambda;
@@ -1155,7 +1174,7 @@ void gauss_parameters(const Node& g, double z, double out[4]) {
     double w = std::sqrt(y_d * y_d + y_w * y_w);
     double R = E_kt / (w * w);
     double zz = E_kt / (F_kt * F_kt);
-    double psi = -std::atan2(1.0, std::sqrt(1 / (R * zz) - 1));
+    double psi = -trig::atan2(1.0, std::sqrt(1 / (R * zz) - 1));
     double w0 = H / (n * F_kt);
     if (std::isnan(R)) R = 0;
     if (std::isnan(psi)) psi = 0;
@@ -1798,6 +1817,21 @@ double bmo_cpu_sdf(const bmo_scene_desc* desc, int shape, const double* p) {
     Scene S;
     if (!build_scene(desc, S)) return std::numeric_limits<double>::quiet_NaN();
     return sdf_d(S, shape, D3{p[0], p[1], p[2]});
+}
+// jl_trig.hpp's functions one by one (tests/test_jl_trig.py): which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan(y, x)
+double bmo_cpu_jl_trig(int which, double x, double y) {
+    switch (which) {
+        case 0: return jlm::sin(x);
+        case 1: return jlm::cos(x);
+        case 2: return jlm::tan(x);
+        case 3: return jlm::acos(x);
+        case 4: return jlm::atan(x);
+        case 5: return jlm::atan2(y, x);
+    }
+    return NAN;
+}
+void bmo_cpu_jl_trig_n(int which, const double* x, const double* y, long long n, double* out) {
+    for (long long i = 0; i < n; ++i) out[i] = bmo_cpu_jl_trig(which, x[i], y ? y[i] : 0.0);
 }
 int bmo_cpu_normal3d(const bmo_scene_desc* desc, int shape, const double* p, double* n_out) {
     Scene S;

@@ -43,6 +43,10 @@ def lib():
         L.bmo_cpu_reflection3d.argtypes = [dp, dp, dp]
         L.bmo_cpu_refraction3d.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_fresnel.argtypes = [C.c_double, C.c_double, dp]
+        L.bmo_cpu_jl_trig.restype = C.c_double
+        L.bmo_cpu_jl_trig.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.bmo_cpu_jl_trig_n.restype = None
+        L.bmo_cpu_jl_trig_n.argtypes = [C.c_int, dp, dp, C.c_longlong, dp]
         L.bmo_cpu_isentering.argtypes = [dp, dp]
         L.bmo_cpu_refraction3d_ray.argtypes = [dp, dp, C.c_double, C.c_double, dp]
         L.bmo_cpu_global_E0.argtypes = [dp, dp, dp, dp, dp, dp]
@@ -213,6 +217,21 @@ def fresnel_coefficients(theta, n):
     o, po = _d(np.zeros(8))
     lib().bmo_cpu_fresnel(theta, n, po)
     return complex(o[0], o[1]), complex(o[2], o[3]), complex(o[4], o[5]), complex(o[6], o[7])
+
+
+JL_TRIG = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "atan": 4, "atan2": 5}
+
+
+def jl_trig(name, x, y=None):
+    """oracle/jl_trig.hpp (Julia Base's sin / cos / tan / acos / atan / atan(y, x)) on an array of arguments."""
+    xs, px = _d(np.atleast_1d(x))
+    out, po = _d(np.zeros(xs.shape[0]))
+    if y is not None:
+        ys, py = _d(np.atleast_1d(y))
+    else:
+        py = None
+    lib().bmo_cpu_jl_trig_n(JL_TRIG[name], px, py, xs.shape[0], po)
+    return out
 
 
 def psf_intensity(hits, origin, e1, e2, xs, zs):

@@ -654,6 +654,14 @@ void run_gauss(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace
 }  // namespace
 
 extern "C" {
+// the lane code's elementary functions one by one (bmo_jlmath.hpp; tests/test_jl_trig.py): 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan(y, x)
+void bmo_emu_jl_trig_n(int which, const double* x, const double* y, long long n, double* out) {
+    for (long long i = 0; i < n; ++i) {
+        const double a = x[i], b = y ? y[i] : 0.0;
+        out[i] = which == 0 ? bmo::jl::sin(a) : which == 1 ? bmo::jl::cos(a) : which == 2 ? bmo::jl::tan(a) : which == 3 ? bmo::jl::acos(a)
+               : which == 4 ? bmo::jl::atan(a) : bmo::jl::atan2(b, a);
+    }
+}
 int bmo_emu_trace(const bmo_scene_desc* d, const bmo_ray_batch* in, const bmo_trace_opts* opts, void** handle, bmo_trace_result_view* v) {
     auto* R = new ResultE();
     try {

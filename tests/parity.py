@@ -12,19 +12,38 @@ EMU = os.path.join(ROOT, "tests", "emu", "libbmo_emu.so")
 _emu = None
 
 
-def emu_trace(scene, bundle, r_max=100, prev=None, max_beams=0):
-    """Host build of the engine's lane code (tests/emu) — test-only.  prev = TraceResult of the previous solve => retrace."""
+def emu_lib():
     global _emu
     if _emu is None:
         import subprocess
 
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(EMU)])
         _emu = C.CDLL(EMU)
+        dp = C.POINTER(C.c_double)
+        _emu.bmo_emu_jl_trig_n.restype = None
+        _emu.bmo_emu_jl_trig_n.argtypes = [C.c_int, dp, dp, C.c_longlong, dp]
         _emu.bmo_emu_trace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.POINTER(C.c_void_p),
                                        C.POINTER(abi.ResultView)]
         _emu.bmo_emu_free.argtypes = [C.c_void_p]
         _emu.bmo_emu_retrace.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RayBatch), C.POINTER(abi.TraceOpts), C.POINTER(abi.ResultView),
                                          C.POINTER(C.c_void_p), C.POINTER(abi.ResultView)]
+    return _emu
+
+
+def emu_jl_trig(which, x, y=None):
+    """The lane code's restatement of Julia Base's sin / cos / tan / acos / atan / atan(y, x) (csrc/bmo_jlmath.hpp), host build."""
+    L = emu_lib()
+    dp = C.POINTER(C.c_double)
+    xs = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+    ys = None if y is None else np.ascontiguousarray(np.atleast_1d(y), dtype=np.float64)
+    out = np.zeros(xs.shape[0])
+    L.bmo_emu_jl_trig_n(int(which), xs.ctypes.data_as(dp), None if ys is None else ys.ctypes.data_as(dp), xs.shape[0], out.ctypes.data_as(dp))
+    return out
+
+
+def emu_trace(scene, bundle, r_max=100, prev=None, max_beams=0):
+    """Host build of the engine's lane code (tests/emu) — test-only.  prev = TraceResult of the previous solve => retrace."""
+    _emu = emu_lib()
     batch, keep = bmo.make_batch(scene, bundle)
     o = abi.TraceOpts()
     o.r_max, o.device, o.record_segments, o.max_beams = int(r_max), 0, 1, int(max_beams)

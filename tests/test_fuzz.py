@@ -4,7 +4,8 @@ thin beam splitters, mirrors, detectors; random tilts and decentres) and random 
 CPU: the engine's per-lane code (host emulator build of csrc/bmo_lane.hpp) must reproduce the oracle bit-exactly — this is what
 keeps the engine's result-preserving shortcuts (bounding-sphere culls, nearest-hit prune, union child skipping, hint reuse, start
 classification probe) honest on geometry nobody hand-picked.   GPU: the same scenes through the C ABI.
-Bar as everywhere: ids / counts / tree bit-exact, FP64 planes bit-exact for geometric rays, 1e-10 relative where libm enters.
+Bar as everywhere: ids / counts / tree bit-exact, FP64 planes bit-exact for every beam kind (round 4: no C library enters a trace,
+tests/test_jl_trig.py).
 """
 import math
 
@@ -175,7 +176,7 @@ CASES = [(seed, "ray") for seed in range(101, 165)] + [(seed, "pol") for seed in
 
 
 def _tol(kind):
-    return 0.0 if kind == "ray" else 1e-10
+    return 0.0
 
 
 def _case(seed, kind, n):
@@ -317,7 +318,7 @@ def test_engine_photodetector_field_on_random_scenes(oracle, seed):
         pytest.skip("train ends in a mirror: no detector in this draw")
     g, gsol = _engine_first(lambda: bmo.system._engine_solve(scene, bundle, R_MAX, None, max_beams=_limit(bundle.n)))
     a, osol = oracle.trace(scene, bundle, R_MAX, threads=16, keep=True)
-    compare(g, a, 1e-10, "pd fuzz %d" % seed)
+    compare(g, a, 0.0, "pd fuzz %d" % seed)
     pd = scene.detectors[0]
     fa = np.zeros((len(pd.x), len(pd.y)), dtype=np.complex128)
     fg = fa.copy()

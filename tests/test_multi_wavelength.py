@@ -27,7 +27,7 @@ def test_lane_code_mixed_wavelengths(oracle, kind):
     scene = bmo.CompiledScene(system, bundle.lambdas)
     assert scene.desc.n_lambda == 2
     ref = oracle.trace(scene, bundle, 100, threads=4)
-    compare(emu_trace(scene, bundle, 100), ref, 0.0 if kind == "ray" else 1e-10, "mixed lambda " + kind)
+    compare(emu_trace(scene, bundle, 100), ref, 0.0, "mixed lambda " + kind)
     # dispersion is really in play: the two colours of one start ray end at different detector positions
     h = ref.detector_hits(0)
     assert len(h) >= 2 and not np.allclose(h[0, :3], h[1, :3], rtol=0, atol=1e-9)
@@ -45,4 +45,4 @@ def test_engine_mixed_wavelengths(oracle, kind):
         got = eng.trace(bundle, 100)
     finally:
         eng.close()
-    compare(got, ref, 0.0 if kind == "ray" else 1e-10, "mixed lambda gpu " + kind)
+    compare(got, ref, 0.0, "mixed lambda gpu " + kind)

@@ -224,7 +224,7 @@ def _field_pair(oracle, n, r_max=20):
     scene = bmo.CompiledScene(system, bundle.lambdas)
     a, osol = oracle.trace(scene, bundle, r_max, threads=16, keep=True)
     g, gsol = bmo.system._engine_solve(scene, bundle, r_max, None)
-    compare(g, a, 1e-10, "pd scene")
+    compare(g, a, 0.0, "pd scene")
     fa = np.zeros((len(pd.x), len(pd.y)), dtype=np.complex128)
     fg = fa.copy()
     osol.photodetector_field(0, pd.position(), pd.orientation(), pd.x, pd.y, fa)

@@ -96,14 +96,14 @@ def test_kept_children_lane_code(oracle):
     a1, sol1 = oracle.trace(scene1, bundle, R_MAX, threads=4, keep=True, prev=sol0)
     _check_kept_children(a0, a1, n)
     e0 = emu_trace(scene0, bundle, R_MAX)
-    compare(e0, a0, 1e-10, "kept children: first solve")
+    compare(e0, a0, 0.0, "kept children: first solve")
     e1 = emu_trace(scene1, bundle, R_MAX, prev=e0)
-    compare(e1, a1, 1e-10, "kept children: retrace")
+    compare(e1, a1, 0.0, "kept children: retrace")
     # and back: the filter passes again, the re-walked first ray is the whole stored path -> push!, children dropped, fresh trace (System.jl:241-248)
     a2 = oracle.trace(scene0, bundle, R_MAX, threads=4, prev=sol1)
     e2 = emu_trace(scene0, bundle, R_MAX, prev=e1)
     assert not (a2.node_status & STALE).any()
-    compare(e2, a2, 1e-10, "kept children: retrace back")
+    compare(e2, a2, 0.0, "kept children: retrace back")
 
 
 @pytest.mark.gpu
@@ -115,11 +115,11 @@ def test_kept_children_engine(oracle):
     a2 = oracle.trace(scene0, bundle, R_MAX, threads=16, prev=sol1)
     _check_kept_children(a0, a1, n)
     g0, h0 = _engine_solve(scene0, bundle, R_MAX)
-    compare(g0, a0, 1e-10, "kept children gpu: first solve")
+    compare(g0, a0, 0.0, "kept children gpu: first solve")
     g1, h1 = _engine_solve(scene1, bundle, R_MAX, h0)
-    compare(g1, a1, 1e-10, "kept children gpu: retrace")
+    compare(g1, a1, 0.0, "kept children gpu: retrace")
     g2, h2 = _engine_solve(scene0, bundle, R_MAX, h1)
-    compare(g2, a2, 1e-10, "kept children gpu: retrace back")
+    compare(g2, a2, 0.0, "kept children gpu: retrace back")
     for h in (h0, h1, h2):
         h.free()
 
@@ -175,12 +175,12 @@ def test_stale_tail_lane_code(oracle, with_lens):
     kid = a1.node_first_child[0]
     assert not np.array_equal(fresh.node_aux[kid], a1.node_aux[kid])
     e0 = emu_trace(scene0, bundle, R_MAX)
-    compare(e0, a0, 1e-10, "stale tail: first solve")
+    compare(e0, a0, 0.0, "stale tail: first solve")
     e1 = emu_trace(scene1, bundle, R_MAX, prev=e0)
-    compare(e1, a1, 1e-10, "stale tail: retrace")
+    compare(e1, a1, 0.0, "stale tail: retrace")
     a2 = oracle.trace(scene0, bundle, R_MAX, threads=4, prev=sol1)
     e2 = emu_trace(scene0, bundle, R_MAX, prev=e1)
-    compare(e2, a2, 1e-10, "stale tail: retrace back")
+    compare(e2, a2, 0.0, "stale tail: retrace back")
 
 
 @pytest.mark.gpu
@@ -193,10 +193,10 @@ def test_stale_tail_engine(oracle, with_lens):
     a2 = oracle.trace(scene0, bundle, R_MAX, threads=16, prev=sol1)
     _check_stale_tail(a0, a1, n, with_lens)
     g0, h0 = _engine_solve(scene0, bundle, R_MAX)
-    compare(g0, a0, 1e-10, "stale tail gpu: first solve")
+    compare(g0, a0, 0.0, "stale tail gpu: first solve")
     g1, h1 = _engine_solve(scene1, bundle, R_MAX, h0)
-    compare(g1, a1, 1e-10, "stale tail gpu: retrace")
+    compare(g1, a1, 0.0, "stale tail gpu: retrace")
     g2, h2 = _engine_solve(scene0, bundle, R_MAX, h1)
-    compare(g2, a2, 1e-10, "stale tail gpu: retrace back")
+    compare(g2, a2, 0.0, "stale tail gpu: retrace back")
     for h in (h0, h1, h2):
         h.free()

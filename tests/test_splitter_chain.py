@@ -50,7 +50,7 @@ def test_splitter_chain_lane_code(oracle, kind):
     scene = bmo.CompiledScene(system, b.lambdas)
     ref = oracle.trace(scene, b, 50, threads=8)
     assert ref.n_nodes >= 24 * 9  # every level of the tree splits once more
-    compare(emu_trace(scene, b, 50), ref, 0.0 if kind == "ray" else 1e-10, f"splitter chain, lane code, {kind}")
+    compare(emu_trace(scene, b, 50), ref, 0.0, f"splitter chain, lane code, {kind}")
 
 
 @pytest.mark.gpu
@@ -65,6 +65,6 @@ def test_splitter_chain_engine(oracle, kind, n_split):
     assert ref.n_nodes > 8 * b.n
     eng = bmo.Engine(scene, 0)
     try:
-        compare(eng.trace(b, 50), ref, 0.0 if kind == "ray" else 1e-10, f"splitter chain x{n_split}, engine, {kind}")
+        compare(eng.trace(b, 50), ref, 0.0, f"splitter chain x{n_split}, engine, {kind}")
     finally:
         eng.close()
