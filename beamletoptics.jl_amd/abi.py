@@ -211,6 +211,8 @@ def load_engine():
     lib.bmo_device_count.restype = C.c_int
     lib.bmo_selftest.argtypes = [C.c_int32]
     lib.bmo_selftest.restype = C.c_int
+    lib.bmo_jl_trig.argtypes = [C.c_int32, C.c_double, C.c_double]
+    lib.bmo_jl_trig.restype = C.c_double
     lib.bmo_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     lib.bmo_scene_destroy.argtypes = [vp]
     lib.bmo_trace.argtypes = [vp, C.POINTER(RayBatch), C.POINTER(TraceOpts), C.POINTER(vp)]

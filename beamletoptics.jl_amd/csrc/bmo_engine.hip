@@ -2786,6 +2786,18 @@ int bmo_device_count(void) {
     return n;
 }
 
+double bmo_jl_trig(int32_t which, double x, double y) {
+    switch (which) {
+        case 0: return jl::sin(x);
+        case 1: return jl::cos(x);
+        case 2: return jl::tan(x);
+        case 3: return jl::acos(x);
+        case 4: return jl::atan(x);
+        case 5: return jl::atan2(y, x);
+    }
+    return (double)NAN;
+}
+
 int bmo_selftest(int32_t device) {
     if (hipSetDevice(device) != hipSuccess) return fail(BMO_ERR_NO_DEVICE, "hipSetDevice");
     const double tiny = 4.9406564584124654e-324, big = 1.7976931348623157e308;

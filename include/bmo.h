@@ -296,6 +296,12 @@ int bmo_device_count(void);
    bmo_last_error(). */
 int bmo_selftest(int32_t device);
 
+/* The elementary functions of the step path as the engine evaluates them (csrc/bmo_jlmath.hpp: Julia Base's sin / cos / tan / acos / atan —
+   base/special/trig.jl, rem_pio2.jl — restated; the reference calls them in OpticUtils.jl:121-131, LinearAlgebraUtils.jl:103-108,
+   Gaussian.jl:326-345), host build, one value per call: which = 0 sin(x), 1 cos(x), 2 tan(x), 3 acos(x), 4 atan(x), 5 atan(y, x).  For a
+   maintainer to compare with Base itself; bmo_selftest compares the device's results with these.  NaN for another `which`. */
+double bmo_jl_trig(int32_t which, double x, double y);
+
 int bmo_scene_create(const bmo_scene_desc* desc, bmo_scene** out);
 int bmo_scene_destroy(bmo_scene* scene);
 /* The engine keeps freed device blocks in a per-device pool for reuse by the next trace; this returns them to HIP. */

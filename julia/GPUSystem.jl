@@ -145,6 +145,25 @@ function check_library()
     return LIB_INFO[]
 end
 
+"""
+    check_elementary_functions(; n = 100_000)
+
+The engine does not call a C library for `sin` / `cos` (`fresnel_coefficients`), `acos` (`angle3d`), `tan` and `atan(y, x)` (`gauss_parameters`): it
+evaluates Base's own algorithms (base/special/trig.jl), restated in csrc/bmo_jlmath.hpp, so that a traced `E0` or `w0` carries the bits `solve_system!`
+produces.  The restatement was written without a Julia at hand; this is the one-minute check a maintainer runs once per Julia version: every function on
+`n` random arguments against Base, `==` on the bits.  Returns the number of mismatches per function (all zero = the engine's numerics contract holds here).
+"""
+function check_elementary_functions(; n::Int = 100_000)
+    f(which, x, y = 0.0) = ccall((:bmo_jl_trig, LIBBMO), Cdouble, (Int32, Cdouble, Cdouble), Int32(which), Float64(x), Float64(y))
+    same(a, b) = (isnan(a) && isnan(b)) || reinterpret(UInt64, a) == reinterpret(UInt64, b)
+    xs = 14 .* rand(n) .- 7
+    us = 2 .* rand(n) .- 1
+    ws = randn(n) .* exp.(80 .* rand(n) .- 40)
+    return (sin = count(x -> !same(f(0, x), sin(x)), xs), cos = count(x -> !same(f(1, x), cos(x)), xs),
+            tan = count(x -> !same(f(2, x), tan(x)), xs ./ 4.5), acos = count(x -> !same(f(3, x), acos(x)), us),
+            atan = count(x -> !same(f(4, x), atan(x)), ws), atan2 = count(x -> !same(f(5, x, 1.0), atan(1.0, x)), abs.(ws)))
+end
+
 function check(rc::Cint)
     rc == BMO_OK && return nothing
     msg = unsafe_string(ccall((:bmo_last_error, LIBBMO), Cstring, ()))

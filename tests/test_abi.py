@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "bmo.h")).read()
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(bmo_[a-z_]+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|double|const char\*)\s+(bmo_[a-z_]+)\s*\(", src, flags=re.M)))
 
 
 def test_engine_exports_every_declared_symbol():

@@ -92,3 +92,19 @@ def test_lane_code_equals_oracle_bit_for_bit(oracle, name):
     a = oracle.jl_trig(name, xs, ys)
     b = emu_jl_trig(WHICH[name], xs, ys)
     assert np.array_equal(a.view(np.int64), b.view(np.int64)), (name, xs[np.flatnonzero(a.view(np.int64) != b.view(np.int64))[:5]])
+
+
+def test_engine_library_export_equals_oracle(oracle):
+    """`bmo_jl_trig` (include/bmo.h): the host build of csrc/bmo_jlmath.hpp inside the engine library — what `bmo_selftest` compares the device with
+    and what a maintainer compares with Base (julia/GPUSystem.jl `check_elementary_functions`).  Loads without a GPU."""
+    import bmo_amd as bmo
+
+    lib = bmo.abi.load_engine()
+    rng = np.random.default_rng(11)
+    for name, which in WHICH.items():
+        xs = rng.uniform(-1, 1, 4000) if name == "acos" else rng.uniform(-7, 7, 4000)
+        ys = np.ones(4000) if name == "atan2" else None
+        want = oracle.jl_trig(name, xs, ys)
+        got = np.array([lib.bmo_jl_trig(which, float(x), 1.0) for x in xs])
+        assert np.array_equal(want.view(np.int64), got.view(np.int64)), name
+    assert math.isnan(lib.bmo_jl_trig(9, 0.5, 0.0))
