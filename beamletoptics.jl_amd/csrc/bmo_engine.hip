@@ -2720,14 +2720,15 @@ __global__ void selftest_minmax_kernel(const double* __restrict__ v, int n, int3
     if (!same(jmax(x, y), jmax_rule(x, y))) form = 1;
     else if (!same(jmin(x, y), jmin_rule(x, y))) form = 2;
     else {
-        // Dual forms: value as above, partials of the winner (x on ties)
+        // Dual forms: the winner's value and partials
         const Dual X{x, {1.0, 2.0, 3.0}}, Y{y, {5.0, 6.0, 7.0}};
         const Dual mx = jmax(X, Y), mn = jmin(X, Y), mx0 = jmax(X, y), mn0 = jmin(X, y);
-        const bool ywx = (y > x) || (sgn(y) < sgn(x)), ywn = (y < x) || (sgn(y) > sgn(x));
-        if (!same(mx.v, jmax_rule(x, y)) || mx.p[0] != (ywx ? 5.0 : 1.0) || mx.p[2] != (ywx ? 7.0 : 3.0)) form = 3;
-        else if (!same(mn.v, jmin_rule(x, y)) || mn.p[0] != (ywn ? 5.0 : 1.0) || mn.p[2] != (ywn ? 7.0 : 3.0)) form = 4;
-        else if (!same(mx0.v, jmax_rule(x, y)) || mx0.p[1] != (ywx ? 0.0 : 2.0)) form = 5;
-        else if (!same(mn0.v, jmin_rule(x, y)) || mn0.p[1] != (ywn ? 0.0 : 2.0)) form = 6;
+        // (selection, ties and unordered operands to the second argument: bmo_lane.hpp above jsqrt(DualN))
+        const bool xwx = x > y, xwn = x < y;
+        if (!same(mx.v, xwx ? x : y) || mx.p[0] != (xwx ? 1.0 : 5.0) || mx.p[2] != (xwx ? 3.0 : 7.0)) form = 3;
+        else if (!same(mn.v, xwn ? x : y) || mn.p[0] != (xwn ? 1.0 : 5.0) || mn.p[2] != (xwn ? 3.0 : 7.0)) form = 4;
+        else if (!same(mx0.v, xwx ? x : y) || mx0.p[1] != (xwx ? 2.0 : 0.0)) form = 5;
+        else if (!same(mn0.v, xwn ? x : y) || mn0.p[1] != (xwn ? 2.0 : 0.0)) form = 6;
         const Dual ab = jabs(X);
         if (!form && (!same(ab.v, fabs(x)) || ab.p[0] != (sgn(x) ? -1.0 : 1.0))) form = 7;
     }

@@ -231,18 +231,22 @@ BMO_DN DualN<N> operator/(const DualN<N>& x, double c) {
     for (int q = 0; q < N; ++q) r.p[q] = x.p[q] / c;
     return r;
 }
+// The dual-number rules below are the ones under which EVERY reference KAT holds at its original assertion (oracle/RULE_TABLE.md, round 4):
+//   sqrt: deriv * partials as ForwardDiff writes it — at 0 the derivative is Inf, a zero partial becomes 0 * Inf = NaN (rounds 1 - 3 kept zero
+//         partials zero);
+//   max / min: SELECTION — the winner's value and partials and nothing else (rounds 1 - 3: DiffRules' product form dvx * px + dvy * py, in
+//         which a NaN partial of the LOSING operand poisons the result), ties go to the SECOND argument (`x > y ? x : y`, `x < y ? x : y`), a
+//         Real operand counts as a Dual with zero partials.
+// What they do together: `norm(max.(q, 0))` of a zero vector is NaN; where it sits in the winning operand of a shape's outer max (the flat
+// faces of boxes and prisms: runtests.jl:2629-2630 needs the central-difference normal there) the normal falls back to the numeric gradient
+// (AbstractSDF.jl:90-95), where it sits in the losing operand (every hit on a concave spherical surface: runtests.jl:2755-2761 needs the dual
+// normal there) it is dropped, and at a concave apex, where the operands tie, the clean second one wins (runtests.jl:1309-1314).
 BMO_DN DualN<N> jsqrt(const DualN<N>& x) {
     const double s = sqrt(x.v);
     const double d = 1.0 / (2.0 * s);
-    // sqrt(0) with zero partials keeps them zero (ForwardDiff's NaN-safe partial scaling; pinned by the reference's narrow point-source KAT,
-    // test/runtests.jl:2755-2761 — see oracle/jl_math.hpp).  The rule reads "ALL partials zero"; it is applied partial by partial here, which
-    // is the same thing wherever it can matter: every sqrt of the leaves takes a sum of squares, and a sum of squares that is exactly 0 has
-    // every term 0 and with it every partial (2 u du = 0 du) — a zero value with a non-zero partial next to a zero one does not occur, and
-    // if an earlier non-finite partial made it occur, that partial stays non-finite and the normal falls back to the numeric gradient either way.
-    const bool at_zero = !(fabs(d) < kinf());
     DualN<N> r;
     r.v = s;
-    for (int q = 0; q < N; ++q) r.p[q] = (at_zero && x.p[q] == 0) ? x.p[q] : x.p[q] * d;  // selects, not a branch
+    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * d;
     return r;
 }
 BMO_DN DualN<N> jabs(const DualN<N>& x) {
@@ -253,33 +257,31 @@ BMO_DN DualN<N> jabs(const DualN<N>& x) {
     return r;
 }
 BMO_DN DualN<N> jmax(const DualN<N>& x, const DualN<N>& y) {
-    const bool yw = (y.v > x.v) | (sgn(y.v) < sgn(x.v));
-    const double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    const bool xw = x.v > y.v;
     DualN<N> r;
-    r.v = jmax(x.v, y.v);
-    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * dx) + (y.p[q] * dy);
+    r.v = xw ? x.v : y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = xw ? x.p[q] : y.p[q];
     return r;
 }
 BMO_DN DualN<N> jmin(const DualN<N>& x, const DualN<N>& y) {
-    const bool yw = (y.v < x.v) | (sgn(y.v) > sgn(x.v));
-    const double dx = yw ? 0.0 : 1.0, dy = yw ? 1.0 : 0.0;
+    const bool xw = x.v < y.v;
     DualN<N> r;
-    r.v = jmin(x.v, y.v);
-    for (int q = 0; q < N; ++q) r.p[q] = (x.p[q] * dx) + (y.p[q] * dy);
+    r.v = xw ? x.v : y.v;
+    for (int q = 0; q < N; ++q) r.p[q] = xw ? x.p[q] : y.p[q];
     return r;
 }
 BMO_DN DualN<N> jmax(const DualN<N>& x, double y) {
-    const double dx = ((y > x.v) | (sgn(y) < sgn(x.v))) ? 0.0 : 1.0;
+    const bool xw = x.v > y;
     DualN<N> r;
-    r.v = jmax(x.v, y);
-    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * dx;
+    r.v = xw ? x.v : y;
+    for (int q = 0; q < N; ++q) r.p[q] = xw ? x.p[q] : 0.0;
     return r;
 }
 BMO_DN DualN<N> jmin(const DualN<N>& x, double y) {
-    const double dx = ((y < x.v) | (sgn(y) > sgn(x.v))) ? 0.0 : 1.0;
+    const bool xw = x.v < y;
     DualN<N> r;
-    r.v = jmin(x.v, y);
-    for (int q = 0; q < N; ++q) r.p[q] = x.p[q] * dx;
+    r.v = xw ? x.v : y;
+    for (int q = 0; q < N; ++q) r.p[q] = xw ? x.p[q] : 0.0;
     return r;
 }
 

@@ -290,10 +290,11 @@ const char* bmo_build_flags_hash(void);
 int bmo_device_count(void);
 
 /* Device self-test of the scalar rules of the lane code as the device compiler built them: Base.max / Base.min for Float64 (NaN if
-   either operand is NaN, -0.0 < +0.0; the AbstractSDF leaf formulas), their ForwardDiff.Dual forms (partials of the winner) and
-   abs(::Dual), written without control flow, against the rule written with compares, bit for bit over every pair of a table of
-   special values (zeros, denormals, infinities, NaN, ordinary numbers).  BMO_OK, or BMO_ERR_INTERNAL with the first mismatch in
-   bmo_last_error(). */
+   either operand is NaN, -0.0 < +0.0; the AbstractSDF leaf formulas) written without control flow against the rule written with compares,
+   their ForwardDiff.Dual forms (selection: the winner's value and partials, ties to the second argument) and abs(::Dual), bit for bit over
+   every pair of a table of special values (zeros, denormals, infinities, NaN, ordinary numbers); then the elementary functions of
+   csrc/bmo_jlmath.hpp on ~7 000 arguments against the host build of the same code.  BMO_OK, or BMO_ERR_INTERNAL with the first mismatch
+   in bmo_last_error(). */
 int bmo_selftest(int32_t device);
 
 /* The elementary functions of the step path as the engine evaluates them (csrc/bmo_jlmath.hpp: Julia Base's sin / cos / tan / acos / atan —

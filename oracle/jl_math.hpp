@@ -21,8 +21,8 @@
 // ---------------------------------------------------------------------------
 // Rule-set switches for the UNPINNED third-party arithmetic (oracle/rule_table.py builds every combination and runs the transcribed
 // reference KATs, the two exact ones at their original assertions, over the product; the table is oracle/RULE_TABLE.md):
-//   BMO_RULE_SQRT0  0  sqrt(Dual(0, zeros)) keeps zero partials (ForwardDiff NaN-safe partial scaling; THE DEFAULT, see jsqrt below)
-//                   1  0 * Inf = NaN (default ForwardDiff: deriv * partials)                     [-DBMO_SQRT_PLAIN is the old spelling]
+//   BMO_RULE_SQRT0  0  sqrt(Dual(0, zeros)) keeps zero partials (ForwardDiff's NaN-safe partial scaling; the default of rounds 1 - 3)
+//                   1  0 * Inf = NaN (default ForwardDiff: deriv * partials)           THE DEFAULT  [-DBMO_SQRT_PLAIN is the old spelling]
 //   BMO_RULE_TIE    0  max / min(::Dual, ::Real) at EQUAL values and equal zero signs: the Dual operand wins and keeps its partials
 //                      (DiffRules: y wins iff (y > x) | (signbit(y) < signbit(x)))                       THE DEFAULT
 //                   1  the Real operand wins the tie (zero partials), as an `ifelse(x > y, x, y)` style definition would give
@@ -33,13 +33,26 @@
 #define BMO_RULE_SQRT0 1
 #endif
 #ifndef BMO_RULE_SQRT0
-#define BMO_RULE_SQRT0 0
+#define BMO_RULE_SQRT0 1
 #endif
 #ifndef BMO_RULE_TIE
 #define BMO_RULE_TIE 0
 #endif
 #ifndef BMO_RULE_NORM0
 #define BMO_RULE_NORM0 0
+#endif
+//   BMO_RULE_SELECT 0  max / min of Duals in DiffRules' product form dvx * px + dvy * py: a NaN partial of the LOSING operand poisons the
+//                      result (0 * NaN)                                                              (the default of rounds 1 - 3)
+//                   1  max / min by SELECTION: the winner's value and partials and nothing else; a Real operand is promoted to a Dual with
+//                      zero partials first; ties return the FIRST argument (`ifelse(isless(x, y), y, x)`)
+//                   2  selection, ties return the SECOND argument (`x > y ? x : y`, `x < y ? x : y`)                  THE DEFAULT
+// Round 4 found the one combination under which EVERY transcribed reference KAT holds at its original assertion, the two exact ones included
+// (oracle/RULE_TABLE.md: 67 of 67): SQRT0 = 1, NORM0 = 0, SELECT = 2 with Julia Base's elementary functions.  What decides it: the prism's
+// entry face needs the central-difference normal (`norm(max.(q, 0))` of a zero vector is NaN and sits in the WINNING operand of the sdf's
+// outer `max`), the concave surfaces need their dual normals (the same NaN sits in the LOSING operand there and must not leak), and at the
+// apex of a concave surface the two operands tie — only "the second one wins" keeps the on-axis ray's normal valid.
+#ifndef BMO_RULE_SELECT
+#define BMO_RULE_SELECT 2
 #endif
 
 namespace jl {
@@ -143,6 +156,17 @@ inline Dual jabs(const Dual& a) { return std::signbit(a.v) ? -a : a; }
 //   DiffRules:  max: y wins iff (y > x) | (signbit(y) < signbit(x));  min: (y < x) | (signbit(y) > signbit(x))
 // NOTE the multiplication by 0/1: a NaN/Inf partial of the LOSING operand contaminates the result
 // (0*NaN = NaN).  That is what triggers the numeric-gradient fallback of AbstractSDF.jl:92-94.
+#if BMO_RULE_SELECT == 2  // selection, ties to the SECOND argument: `x > y ? x : y` / `x < y ? x : y`
+inline Dual jmax(const Dual& x, const Dual& y) { return x.v > y.v ? x : y; }
+inline Dual jmin(const Dual& x, const Dual& y) { return x.v < y.v ? x : y; }
+inline Dual jmax(const Dual& x, double y) { return jmax(x, Dual{y, {0, 0, 0}}); }
+inline Dual jmin(const Dual& x, double y) { return jmin(x, Dual{y, {0, 0, 0}}); }
+#elif BMO_RULE_SELECT == 1
+inline Dual jmax(const Dual& x, const Dual& y) { return (x.v < y.v || (x.v == y.v && std::signbit(x.v) > std::signbit(y.v))) ? y : x; }  // isless(x, y) ? y : x
+inline Dual jmin(const Dual& x, const Dual& y) { return (y.v < x.v || (x.v == y.v && std::signbit(y.v) > std::signbit(x.v))) ? y : x; }  // isless(y, x) ? y : x
+inline Dual jmax(const Dual& x, double y) { return jmax(x, Dual{y, {0, 0, 0}}); }
+inline Dual jmin(const Dual& x, double y) { return jmin(x, Dual{y, {0, 0, 0}}); }
+#else
 inline Dual jmax(const Dual& x, const Dual& y) {
     bool ywins = (y.v > x.v) || (std::signbit(y.v) < std::signbit(x.v));
     double dx = ywins ? 0.0 : 1.0, dy = ywins ? 1.0 : 0.0;
@@ -170,7 +194,7 @@ inline Dual jmin(const Dual& x, double y) {
     double dx = ywins ? 0.0 : 1.0;
     return Dual{jmin(x.v, y), {x.p[0] * dx, x.p[1] * dx, x.p[2] * dx}};
 }
-
+#endif
 
 // ---- additional Dual rules used by the aspheric / acylindric SDFs (ForwardDiff dual.jl) ----------------------
 // Dual / Dual: Dual(vx/vy, _div_partials(px, py, vx, vy)), _div_partials(a, b, av, bv) = _mul_partials(a, b, inv(bv), -(av/(bv*bv)))

@@ -57,9 +57,10 @@ def run_kat(solve):
         assert coma_ok(detector, atol)
         # All 1000 rays arrive, the chief ray included: it runs exactly along the axis and leaves the second doublet through the
         # apex of a concave surface, where the cylinder part of ConcaveSphericalSurfaceSDF takes norm() of a zero vector.  This KAT
-        # is what pins the sqrt(0) rule of the dual numbers (oracle/jl_math.hpp jsqrt): with 0*Inf = NaN every concave normal
-        # falls back to central differences, the narrow bundle (all rays within 25 um of the apexes) lands 1e-3 m off instead of
-        # 2e-7 m, and the chief ray gets a NaN normal.
+        # is what pins the max / min rule of the dual numbers (oracle/jl_math.hpp): if the NaN partials of that norm leak through the
+        # sdf's outer max (DiffRules' product form), every concave normal falls back to central differences, the narrow bundle (all
+        # rays within 25 um of the apexes) lands 1e-3 m off instead of 2e-7 m; and if ties go to the first argument the chief ray gets a
+        # NaN normal (refraction3d would throw in the reference).
         lost = [i for i, b in enumerate(src.beams) if b.rays[-1].intersection is None or b.rays[-1].intersection.object is not detector]
         assert lost == [], lost
         assert len(detector.data) == len(src.beams)

@@ -290,9 +290,9 @@ def test_doublet(oracle, lam, bfl, df):  # :1273-1321
         assert np.linalg.norm(p0 - f0) <= 1e-6
     # Centre-ray normals, as the reference tests them (runtests.jl:1309-1314): the exact-axis ray on the ROTATED doublet, every
     # normal parallel to the ray.  The ray ends on the apex of the cemented ConcaveSphericalSurfaceSDF, where the cylinder part of
-    # that sdf takes norm() of a zero vector: with sqrt(0) keeping zero partials (oracle/jl_math.hpp jsqrt) the dual-number normal
-    # is valid and exactly axial; with 0*Inf = NaN the central-difference fallback cancels to rounding noise there and this
-    # assertion cannot hold on the rotated lens — one of the three reference KATs that pin that rule.
+    # that sdf takes norm() of a zero vector (NaN partials) and TIES with the sphere part in the sdf's outer max: the clean second
+    # operand has to win the tie, or the central-difference fallback — which cancels to rounding noise at that apex — takes over
+    # and this assertion cannot hold on the rotated lens.  One of the KATs that pin the max / min rule (oracle/jl_math.hpp).
     beam = bmo.Beam(pos + 0 * nv, -d, lam)
     oracle.solve_system(system, beam)
     assert len(beam.rays) == 4
