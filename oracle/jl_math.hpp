@@ -134,12 +134,17 @@ inline bool operator>(const Dual& a, double b) { return a.v > b; }
 //   degrees.  The reference's "Double Gauss lens / point source (narrow)" test sends 1000 rays through exactly that disc of several
 //   concave surfaces and requires a 2e-7 m spot; measured with this oracle: 1.3e-7 m with zero partials kept, 1e-3 m with NaN
 //   (build with -DBMO_SQRT_PLAIN to see it).  That test passing upstream is incompatible with the NaN variant.
-//   One reference assertion points the other way (the cube splitter rotated by pi/2 returning `direction == [0, 1, 0]` exactly,
+//   One reference assertion seemed to point the other way (the cube splitter rotated by pi/2 returning `direction == [0, 1, 0]` exactly,
 //   runtests.jl:2629-2630, needs the exactly axis-aligned normal that only the numeric fallback yields on the prism's entry face,
-//   where norm(max.(q, 0)) is again the norm of a zero vector); tests/test_oracle_kat2.py keeps it at one unit of cos(pi/2) =
-//   6.1e-17.  Both cannot hold under one rule for the same expression; the physical KAT has a 5000x margin, the exact-equality one
-//   rides on the last bit.  Status: UNPINNED at the bit level until someone runs the reference; the rule is applied in
-//   the oracle and in the engine alike (csrc/bmo_lane.hpp jsqrt), so it cannot make them disagree with each other.
+//   where norm(max.(q, 0)) is again the norm of a zero vector), and rounds 1 - 3 concluded "both cannot hold under one rule for the same
+//   expression".  ROUND 4: they can — the expression is the same, its PLACE is not.  In the prism the NaN term is the operand that WINS the
+//   sdf's outer max(box_dist, pln_dist); in the concave surface it is the operand that LOSES max(sdf1, -sdf2).  With max / min of dual numbers
+//   taken by SELECTION (the winner's partials and nothing else) instead of DiffRules' product form (0 * NaN poisons), sqrt may be the
+//   default ForwardDiff one (NaN at zero) on GeometryBasics' sqrt(dot): the prism falls back to central differences, the concave surfaces
+//   do not, and with ties going to the second argument the on-axis apex (where sdf1 and -sdf2 tie at 0) keeps its dual normal too.  That
+//   rule set passes all 67 transcribed KATs at their original assertions (oracle/RULE_TABLE.md row 1) and is the default now; it is applied in
+//   the oracle and in the engine alike (csrc/bmo_lane.hpp).  Whether upstream's ForwardDiff really selects is still not something that can be
+//   READ here (no package sources); it is what the reference's tests, taken together, leave.
 inline Dual jsqrt(const Dual& a) {
     double s = std::sqrt(a.v);
     double d = 1.0 / (2.0 * s);
@@ -151,11 +156,11 @@ inline Dual jsqrt(const Dual& a) {
 // abs: ForwardDiff dual.jl  Base.abs(d::Dual) = signbit(value(d)) ? -d : d
 inline Dual jabs(const Dual& a) { return std::signbit(a.v) ? -a : a; }
 
-// max/min: ForwardDiff builds them from DiffRules' binary rules:
+// max/min.  BMO_RULE_SELECT = 0 (rounds 1 - 3) is the form one gets when ForwardDiff builds them from DiffRules' binary rules:
 //   Dual(max(vx,vy), _mul_partials(px, py, dvx, dvy)),  (dvx,dvy) in {(1,0),(0,1)}
 //   DiffRules:  max: y wins iff (y > x) | (signbit(y) < signbit(x));  min: (y < x) | (signbit(y) > signbit(x))
-// NOTE the multiplication by 0/1: a NaN/Inf partial of the LOSING operand contaminates the result
-// (0*NaN = NaN).  That is what triggers the numeric-gradient fallback of AbstractSDF.jl:92-94.
+// with the multiplication by 0/1: a NaN/Inf partial of the LOSING operand contaminates the result (0*NaN = NaN).
+// BMO_RULE_SELECT = 2 (the default since round 4, see above jsqrt): plain selection.
 #if BMO_RULE_SELECT == 2  // selection, ties to the SECOND argument: `x > y ? x : y` / `x < y ? x : y`
 inline Dual jmax(const Dual& x, const Dual& y) { return x.v > y.v ? x : y; }
 inline Dual jmin(const Dual& x, const Dual& y) { return x.v < y.v ? x : y; }
