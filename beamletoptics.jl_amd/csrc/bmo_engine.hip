@@ -377,7 +377,7 @@ __device__ __forceinline__ unsigned tile_of_block(int mode, unsigned b, unsigned
 // Waves per SIMD a step-kernel variant is compiled for = its register budget (3: 168 VGPRs, 4: 128).  Round 3: with the scene tables read by scalar
 // loads tracing_step is spill-free at 168 registers, and 3 waves/SIMD beat 2 by 12 % on C2, 17 % on the vignetted bundle and 28 % on C5
 // (profiles/r03_ab_scalar_scene.txt).  Round 4, after the leaf-dispatch work: at 128 registers the Ray kernel of the plain-shapes level spills
-// 100 - 132 B per lane, all of it at bounce-level depth and none inside a march, and the fourth wave is worth more than that — on LARGE launches
+// 60 - 92 B per lane (100 - 132 before the selection-form dual rules), all of it at bounce-level depth and none inside a march, and the fourth wave is worth more than that — on LARGE launches
 // (profiles/r04_ab_scheduling.txt item 14: config 2 - 4 %, config 5 - 9 %, the ragged bundle - 9 %).  A launch of a few thousand waves is as long as its slowest
 // marches, and those run slower with three neighbours on their SIMD than with two (2^18 rays of config 2: + 2 %), so the Ray kernels of that level are
 // compiled twice and the launch picks by its size (`wide_min_waves` below: 4 096 waves, the device filled once at 4 per SIMD).  The other variants are compiled once, for the count that measured faster
