@@ -12,7 +12,7 @@ for w in $WL; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w/stats -- $B --steps 5 --warmup 1 > $O/$w/bench_under_rocprof.json 2> $O/$w/stats.err
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$w/fetch -- $B --steps 1 --warmup 0 > /dev/null 2> $O/$w/fetch.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/$w/write -- $B --steps 1 --warmup 0 > /dev/null 2> $O/$w/write.err
-  if [ $w != c2v ]; then  # SQ + VALU-mix passes for every workload but the ragged one (round 4: c2s is the headline; C4 and C5 had none)
+  if true; then  # SQ + VALU-mix passes for every workload (the ragged one too since the end of round 4: its lane utilisation is the point)
     rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/$w/sq -- $B --steps 1 --warmup 0 > /dev/null 2> $O/$w/sq.err
     rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH --output-format csv -d $O/$w/sq2 -- $B --steps 1 --warmup 0 > /dev/null 2> $O/$w/sq2.err
     rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU --output-format csv -d $O/$w/sq3 -- $B --steps 1 --warmup 0 > /dev/null 2> $O/$w/sq3.err
